@@ -1,0 +1,130 @@
+/* sv3d_hip.h -- C ABI of libsv3d_hip.so, the MI355X (gfx950) hot path of the
+ * CMR-style single-view reconstruction pipeline: soft rasterization forward /
+ * backward and the brute-force Chamfer nearest-neighbour search.
+ *
+ * The reference (pure Python) reaches this arithmetic through two third-party
+ * CUDA extensions.  Each entry point below names the reference call site whose
+ * native dependency it replaces.
+ *
+ * Conventions
+ *   - All pointers are DEVICE pointers to contiguous row-major fp32 / int32
+ *     buffers owned by the caller and borrowed for the call.
+ *   - `stream` is a hipStream_t passed as void*; every call only enqueues work
+ *     on it (no allocation, no host synchronisation), so calls are graph-capture
+ *     safe and re-entrant.  The current HIP device must own the buffers.
+ *   - Return value: SV3D_OK or a negative sv3d_status; sv3d_strerror() names it.
+ *   - Results are bitwise repeatable for fixed inputs: no float atomics to
+ *     global memory anywhere.
+ */
+#ifndef SV3D_HIP_H
+#define SV3D_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum sv3d_status {
+    SV3D_OK = 0,
+    SV3D_ERR_INVALID_ARG = -1,   /* null pointer, non-positive size, bad enum */
+    SV3D_ERR_UNSUPPORTED = -2,   /* size outside what the kernels are built for */
+    SV3D_ERR_WORKSPACE = -3,     /* caller's buffer smaller than sv3d_raster_sizes() says */
+    SV3D_ERR_LAUNCH = -4         /* hipGetLastError() != hipSuccess after a launch */
+} sv3d_status;
+
+enum { SV3D_TEX_NONE = 0, SV3D_TEX_SURFACE = 1, SV3D_TEX_VERTEX = 2 };
+
+/* Rasterizer configuration: the arguments sr.SoftRenderer(...) receives at
+ * nnutils/softras.py:33-37 plus the SoftRas defaults it leaves untouched. */
+typedef struct sv3d_raster_params {
+    int32_t batch;         /* B: images in the render batch                                   */
+    int32_t num_faces;     /* F                                                               */
+    int32_t raster_size;   /* S: resolution the fragments are evaluated at (2*image_size when  */
+                           /*    anti-aliasing)                                               */
+    int32_t aa;            /* 1 or 2: side of the fused average pool; output is S/aa           */
+    int32_t texture_mode;  /* SV3D_TEX_*                                                      */
+    int32_t texture_res;   /* R: surface textures hold R*R texels per face                    */
+    int32_t double_side;   /* SoftRas fill_back: back faces take part in the colour softmax   */
+    int32_t reserved;
+    float background[3];
+    float near_plane;      /* 1   */
+    float far_plane;       /* 100 */
+    float eps;             /* 1e-3: initial softmax maximum                                   */
+    float sigma;           /* sigma_val */
+    float dist_eps;        /* dist_eps as passed by the caller (1e-10), NOT its logit          */
+    float gamma;           /* gamma_val */
+} sv3d_raster_params;
+
+const char *sv3d_strerror(int status);
+int sv3d_abi_version(void);
+
+/* Byte sizes of the buffers the rasterizer calls need:
+ *   face_rec_bytes    per-face setup records written by forward, read by backward
+ *   pixel_saved_bytes per-raster-pixel aggregates written by forward, read by backward
+ *   backward_ws_bytes scratch for backward (contents undefined before and after)      */
+int sv3d_raster_sizes(const sv3d_raster_params *p, size_t *face_rec_bytes,
+                      size_t *pixel_saved_bytes, size_t *backward_ws_bytes);
+
+/* Replaces soft_renderer's `soft_rasterize` forward as reached from
+ * nnutils/softras.py:64,75,77 (sr.SoftRenderer.__call__ / .rasterizer).
+ *   face_vertices [B,F,3,3]  (x, y, z) of the three corners, camera space, y up
+ *   textures      NONE: ignored (may be NULL); SURFACE [B,F,R*R,3]; VERTEX [B,F,3,3]
+ *   rgba_out      [B,4,S/aa,S/aa]   channels R,G,B,alpha, row 0 = top of the image
+ *   face_rec, pixel_saved: see sv3d_raster_sizes                                   */
+int sv3d_raster_forward(const sv3d_raster_params *p, const float *face_vertices,
+                        const float *textures, float *rgba_out, void *face_rec,
+                        void *pixel_saved, void *stream);
+
+/* Replaces soft_renderer's `soft_rasterize` backward (autograd of the call above).
+ *   grad_rgba          [B,4,S/aa,S/aa]
+ *   grad_face_vertices [B,F,3,3]  fully overwritten
+ *   grad_textures      same shape as textures, fully overwritten (NULL for NONE, or
+ *                      when the caller does not need it)                           */
+int sv3d_raster_backward(const sv3d_raster_params *p, const float *textures,
+                         const void *face_rec, const void *pixel_saved,
+                         const float *grad_rgba, float *grad_face_vertices,
+                         float *grad_textures, void *workspace, size_t workspace_bytes,
+                         void *stream);
+
+/* Replaces chamferdist's forward as called at nnutils/loss_utils.py:85-86
+ * (`ChamferDistance()(xyz1, xyz2)`).
+ *   xyz1 [B,N,3], xyz2 [B,M,3] -> dist1 [B,N], dist2 [B,M] (SQUARED distances),
+ *   idx1 [B,N], idx2 [B,M] (int32 index of the nearest point of the other cloud;
+ *   the lowest index wins ties).
+ *   d = fmaf(dz,dz,fmaf(dy,dy,dx*dx)) with dx = other - own, each in fp32.         */
+int sv3d_chamfer_forward(const float *xyz1, const float *xyz2, int32_t B, int32_t N, int32_t M,
+                         float *dist1, float *dist2, int32_t *idx1, int32_t *idx2, void *stream);
+
+/* Replaces chamferdist's backward (autograd of the call above; only dist2 carries a
+ * gradient in the reference, nnutils/loss_utils.py:87-88).
+ *   grad_dist1 [B,N] / grad_dist2 [B,M]: either may be NULL (treated as zero)
+ *   grad_xyz1 [B,N,3] / grad_xyz2 [B,M,3]: either may be NULL (not computed);
+ *   the ones given are fully overwritten.                                          */
+int sv3d_chamfer_backward(const float *xyz1, const float *xyz2, int32_t B, int32_t N, int32_t M,
+                          const float *grad_dist1, const float *grad_dist2,
+                          const int32_t *idx1, const int32_t *idx2,
+                          float *grad_xyz1, float *grad_xyz2, void *stream);
+
+/* Replaces sr.Mesh's `vertices[faces]` gather (soft_renderer Mesh.face_vertices,
+ * reached from nnutils/softras.py:64,72,77) fused with the renderer's affine
+ * pre-stage: out[b,f,k,c] = values[b, faces[fb,f,k], c] * scale[c] + shift[c]
+ * (the y flip of softras.py:60 and the look_at z shift are a scale / shift).
+ *   values [B,V,3]; faces [FB,F,3] int32 with FB == B or FB == 1 (shared topology);
+ *   scale, shift: 3 floats each, HOST pointers (read during the call), NULL = identity */
+int sv3d_face_gather(const float *values, const int32_t *faces, int32_t B, int32_t V, int32_t F,
+                     int32_t faces_batch, const float *scale, const float *shift,
+                     float *out, void *stream);
+
+/* Backward of sv3d_face_gather (autograd of the `vertices[faces]` gather):
+ * grad_values[b,v,c] = scale[c] * sum of grad_out[b,f,k,c] over the corners (f,k) with
+ * faces[fb,f,k] == v, summed in ascending (f,k) order.  Gather form: no atomics, no
+ * index to prepare, bitwise repeatable.  grad_values [B,V,3] is fully overwritten.   */
+int sv3d_face_scatter(const float *grad_out, const int32_t *faces, int32_t B, int32_t V, int32_t F,
+                      int32_t faces_batch, const float *scale, float *grad_values, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SV3D_HIP_H */

@@ -1,0 +1,233 @@
+// Brute-force Chamfer nearest-neighbour search for gfx950 (MI355X).
+//
+// Replaces the chamferdist extension called at nnutils/loss_utils.py:85-86.
+// Forward: for every point of one cloud, the minimum squared distance to the other
+// cloud and the (lowest) index where it is attained.  FP32 VALU bound: 8 FLOP per
+// (query, candidate) pair on 12 bytes per point.
+//
+// Layout of one workgroup (256 threads = 4 waves):
+//   * 64*Q query points live in registers, Q per lane, the SAME queries in all 4 waves;
+//   * candidate points are staged through LDS in tiles of TILE points padded to
+//     float4, so one broadcast ds_read_b128 feeds Q distance evaluations;
+//   * wave w scans quarter w of every tile, so each wave sees its candidates in
+//     increasing index order and a strict `<` keeps the lowest index; the four
+//     per-wave results are merged through LDS by (distance, index) lexicographic
+//     order, which is the global "lowest index among the minima".
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "sv3d_hip.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kWaves = 4;
+constexpr int kTile = 1024;          // candidates staged per LDS tile (16 KiB)
+
+template <int Q>
+__global__ __launch_bounds__(kThreads) void chamfer_nn_kernel(
+    const float *__restrict__ xyz1, const float *__restrict__ xyz2, int N, int M,
+    float *__restrict__ dist1, float *__restrict__ dist2,
+    int32_t *__restrict__ idx1, int32_t *__restrict__ idx2, int blocks_dir0)
+{
+    __shared__ float4 s_pts[kTile];
+    __shared__ float s_best[kWaves][64 * Q];
+    __shared__ int s_bidx[kWaves][64 * Q];
+
+    const int b = blockIdx.y;
+    // direction 0: queries = cloud 1, candidates = cloud 2; direction 1: swapped
+    const bool dir1 = (int)blockIdx.x >= blocks_dir0;
+    const int qblock = dir1 ? (int)blockIdx.x - blocks_dir0 : (int)blockIdx.x;
+    const int nq = dir1 ? M : N;
+    const int nc = dir1 ? N : M;
+    const float *qp = (dir1 ? xyz2 + (size_t)b * M * 3 : xyz1 + (size_t)b * N * 3);
+    const float *cp = (dir1 ? xyz1 + (size_t)b * N * 3 : xyz2 + (size_t)b * M * 3);
+    float *dout = (dir1 ? dist2 + (size_t)b * M : dist1 + (size_t)b * N);
+    int32_t *iout = (dir1 ? idx2 + (size_t)b * M : idx1 + (size_t)b * N);
+
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int q0 = qblock * 64 * Q;
+
+    float qx[Q], qy[Q], qz[Q], best[Q];
+    int bi[Q];
+#pragma unroll
+    for (int k = 0; k < Q; ++k) {
+        const int qi = min(q0 + k * 64 + lane, nq - 1);      // clamp: tail lanes redo the last point
+        qx[k] = qp[3 * qi];
+        qy[k] = qp[3 * qi + 1];
+        qz[k] = qp[3 * qi + 2];
+        best[k] = INFINITY;
+        bi[k] = 0;
+    }
+
+    for (int t0 = 0; t0 < nc; t0 += kTile) {
+        const int tn = min(kTile, nc - t0);
+        __syncthreads();
+        for (int j = threadIdx.x; j < tn; j += kThreads) {
+            const float *c = cp + 3 * (size_t)(t0 + j);
+            s_pts[j] = make_float4(c[0], c[1], c[2], 0.f);
+        }
+        __syncthreads();
+        const int quarter = (tn + kWaves - 1) / kWaves;
+        const int jb = wave * quarter;
+        const int je = min(jb + quarter, tn);
+        for (int j = jb; j < je; ++j) {
+            const float4 c = s_pts[j];
+            const int gj = t0 + j;
+#pragma unroll
+            for (int k = 0; k < Q; ++k) {
+                const float dx = c.x - qx[k];
+                const float dy = c.y - qy[k];
+                const float dz = c.z - qz[k];
+                const float d = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+                const bool lt = d < best[k];
+                best[k] = lt ? d : best[k];
+                bi[k] = lt ? gj : bi[k];
+            }
+        }
+    }
+
+#pragma unroll
+    for (int k = 0; k < Q; ++k) {
+        s_best[wave][k * 64 + lane] = best[k];
+        s_bidx[wave][k * 64 + lane] = bi[k];
+    }
+    __syncthreads();
+    for (int s = threadIdx.x; s < 64 * Q; s += kThreads) {
+        float bd = s_best[0][s];
+        int bj = s_bidx[0][s];
+#pragma unroll
+        for (int w = 1; w < kWaves; ++w) {
+            const float d = s_best[w][s];
+            const int j = s_bidx[w][s];
+            if (d < bd || (d == bd && j < bj)) {
+                bd = d;
+                bj = j;
+            }
+        }
+        const int k = s >> 6, l = s & 63;
+        const int qi = q0 + k * 64 + l;
+        if (qi < nq) {
+            dout[qi] = bd;
+            iout[qi] = bj;
+        }
+    }
+}
+
+// Backward with the indices frozen.  One thread per (direction, batch, own point):
+//   own term   g_own[i]  = 2 gd_own[i] (own[i] - other[idx_own[i]])
+//   scattered  g_own[i] -= sum over j with idx_other[j] == i of 2 gd_other[j] (other[j] - own[i])
+// The scatter is evaluated as a gather: every thread scans the other cloud's index array
+// (staged through LDS) in ascending j, so the sum order is fixed and no atomics are needed.
+__global__ __launch_bounds__(kThreads) void chamfer_grad_kernel(
+    const float *__restrict__ xyz1, const float *__restrict__ xyz2, int N, int M,
+    const float *__restrict__ gd1, const float *__restrict__ gd2,
+    const int32_t *__restrict__ idx1, const int32_t *__restrict__ idx2,
+    float *__restrict__ g1, float *__restrict__ g2, int blocks_dir0)
+{
+    __shared__ int s_idx[kTile];
+    __shared__ float s_g[kTile];
+
+    const int b = blockIdx.y;
+    const bool dir1 = (int)blockIdx.x >= blocks_dir0;
+    const int qblock = dir1 ? (int)blockIdx.x - blocks_dir0 : (int)blockIdx.x;
+    const int n_own = dir1 ? M : N;
+    const int n_oth = dir1 ? N : M;
+    const float *own = dir1 ? xyz2 + (size_t)b * M * 3 : xyz1 + (size_t)b * N * 3;
+    const float *oth = dir1 ? xyz1 + (size_t)b * N * 3 : xyz2 + (size_t)b * M * 3;
+    const float *gd_own = dir1 ? gd2 : gd1;
+    const float *gd_oth = dir1 ? gd1 : gd2;
+    const int32_t *idx_own = dir1 ? idx2 + (size_t)b * M : idx1 + (size_t)b * N;
+    const int32_t *idx_oth = dir1 ? idx1 + (size_t)b * N : idx2 + (size_t)b * M;
+    float *gout = dir1 ? g2 : g1;
+    if (gout == nullptr) return;                         // uniform over the block
+    gout += (size_t)b * n_own * 3;
+
+    const int i = qblock * kThreads + threadIdx.x;
+    const bool live = i < n_own;
+    const int ic = live ? i : n_own - 1;
+    const float ox = own[3 * ic], oy = own[3 * ic + 1], oz = own[3 * ic + 2];
+    float ax = 0.f, ay = 0.f, az = 0.f;
+    if (gd_own != nullptr) {
+        const int j = idx_own[ic];
+        const float g = 2.f * gd_own[(size_t)b * n_own + ic];
+        ax = g * (ox - oth[3 * j]);
+        ay = g * (oy - oth[3 * j + 1]);
+        az = g * (oz - oth[3 * j + 2]);
+    }
+    if (gd_oth != nullptr) {
+        for (int t0 = 0; t0 < n_oth; t0 += kTile) {
+            const int tn = min(kTile, n_oth - t0);
+            __syncthreads();
+            for (int j = threadIdx.x; j < tn; j += kThreads) {
+                s_idx[j] = idx_oth[t0 + j];
+                s_g[j] = 2.f * gd_oth[(size_t)b * n_oth + t0 + j];
+            }
+            __syncthreads();
+            for (int j = 0; j < tn; ++j) {
+                if (s_idx[j] == i) {
+                    const float g = s_g[j];
+                    const float *o = oth + 3 * (size_t)(t0 + j);
+                    ax -= g * (o[0] - ox);
+                    ay -= g * (o[1] - oy);
+                    az -= g * (o[2] - oz);
+                }
+            }
+        }
+    }
+    if (live) {
+        gout[3 * i] = ax;
+        gout[3 * i + 1] = ay;
+        gout[3 * i + 2] = az;
+    }
+}
+
+inline int launch_status()
+{
+    return hipGetLastError() == hipSuccess ? SV3D_OK : SV3D_ERR_LAUNCH;
+}
+
+}  // namespace
+
+extern "C" int sv3d_chamfer_forward(const float *xyz1, const float *xyz2, int32_t B, int32_t N,
+                                    int32_t M, float *dist1, float *dist2, int32_t *idx1,
+                                    int32_t *idx2, void *stream)
+{
+    if (!xyz1 || !xyz2 || !dist1 || !dist2 || !idx1 || !idx2) return SV3D_ERR_INVALID_ARG;
+    if (B <= 0 || N <= 0 || M <= 0) return SV3D_ERR_INVALID_ARG;
+    if (B > 65535) return SV3D_ERR_UNSUPPORTED;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    // Q queries per lane: more reuse of each staged candidate once there is enough work
+    // to keep 256 CUs busy with the smaller grid.
+    const long total = (long)B * ((long)N + M);
+    const int Q = total >= 4L * 256 * 64 * 4 ? 4 : (total >= 4L * 256 * 64 * 2 ? 2 : 1);
+    const int per = 64 * Q;
+    const int b0 = (N + per - 1) / per, b1 = (M + per - 1) / per;
+    dim3 grid(b0 + b1, B), block(kThreads);
+    if (Q == 4)
+        hipLaunchKernelGGL(chamfer_nn_kernel<4>, grid, block, 0, s, xyz1, xyz2, N, M, dist1, dist2, idx1, idx2, b0);
+    else if (Q == 2)
+        hipLaunchKernelGGL(chamfer_nn_kernel<2>, grid, block, 0, s, xyz1, xyz2, N, M, dist1, dist2, idx1, idx2, b0);
+    else
+        hipLaunchKernelGGL(chamfer_nn_kernel<1>, grid, block, 0, s, xyz1, xyz2, N, M, dist1, dist2, idx1, idx2, b0);
+    return launch_status();
+}
+
+extern "C" int sv3d_chamfer_backward(const float *xyz1, const float *xyz2, int32_t B, int32_t N,
+                                     int32_t M, const float *grad_dist1, const float *grad_dist2,
+                                     const int32_t *idx1, const int32_t *idx2, float *grad_xyz1,
+                                     float *grad_xyz2, void *stream)
+{
+    if (!xyz1 || !xyz2 || !idx1 || !idx2) return SV3D_ERR_INVALID_ARG;
+    if (B <= 0 || N <= 0 || M <= 0) return SV3D_ERR_INVALID_ARG;
+    if (B > 65535) return SV3D_ERR_UNSUPPORTED;
+    if (!grad_xyz1 && !grad_xyz2) return SV3D_OK;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int b0 = (N + kThreads - 1) / kThreads, b1 = (M + kThreads - 1) / kThreads;
+    dim3 grid(b0 + b1, B), block(kThreads);
+    hipLaunchKernelGGL(chamfer_grad_kernel, grid, block, 0, s, xyz1, xyz2, N, M, grad_dist1,
+                       grad_dist2, idx1, idx2, grad_xyz1, grad_xyz2, b0);
+    return launch_status();
+}

@@ -1,0 +1,735 @@
+// Soft rasterizer for gfx950 (MI355X): forward and backward.
+//
+// Replaces the soft_renderer CUDA extension reached from nnutils/softras.py:64,75,77.
+// The arithmetic is FP32 VALU work (no contraction, so no MFMA).  Each pass is organised
+// around its OUTPUT so that nothing is scattered:
+//
+//   setup     one thread per face: pixel-independent coefficients ("face record", 32 floats)
+//             and the face's pixel bounding box (the formula's own cull box).
+//   forward   one workgroup per 16x16 pixel tile, one pixel per lane, one wave per 8x8
+//             block.  Faces whose box touches the tile are compacted IN FACE ORDER into an
+//             LDS list, their records staged in LDS, and each wave walks the sub-list that
+//             touches its block (ballot over 64 records at a time), reading every record by
+//             broadcast ds_read_b128.  A pixel reduces over faces in registers.
+//   backward  one WAVE per face, lanes enumerate the pixels of the face's box 64 at a time.
+//             A face reduces over pixels in registers; one fixed-tree DPP reduction per face
+//             at the end; each gradient element is written exactly once.  No atomics to
+//             global memory, bitwise repeatable.
+//
+// Numerics: distances are evaluated in pixel-relative coordinates (vertex minus pixel
+// centre) as point-to-segment distances, which is the same quantity the barycentric
+// `t - w` algebra of SoftRas produces but without its cancellation; depth enters the
+// z-softmax as zp - z_ref (z_ref = first vertex depth of the image) so that the 1/gamma
+// amplification acts on a small, exactly representable offset.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "sv3d_hip.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kRec = 32;          // floats per face record (128 B, eight float4)
+constexpr int kRec4 = kRec / 4;
+constexpr int kTile = 16;         // tile side in raster pixels
+constexpr int kListCap = 256;     // faces staged in LDS at a time (32 KiB)
+
+struct DevParams {
+    int B, F, S, aa, mode, R, double_side;
+    float bg0, bg1, bg2;
+    float near_plane, far_plane, eps;
+    float neg_l2e_over_sigma;     // -log2(e) / sigma
+    float inv_sigma;
+    float threshold;              // ln(1/dist_eps - 1) * sigma
+    float margin;                 // sqrt(threshold)
+    float l2e_over_gamma;         // log2(e) / gamma
+    float inv_gamma;
+    float inv_range;              // 1 / (far - near)
+    float ssum0;                  // exp(eps / gamma): weight of the background term
+};
+
+// Face record layout (float index):
+//  0..5   p0x p0y p1x p1y p2x p2y
+//  6..11  e0x e0y e1x e1y e2x e2y        e_k = p_{k+1} - p_k
+// 12..14  1/|e_k|^2 (0 for a zero-length edge)
+// 15      1/det, det = cross(p1-p0, p2-p0) clamped away from 0 by 1e-10
+// 16..19  cull box: xmin-margin, xmax+margin, ymin-margin, ymax+margin
+// 20..22  1/z_k
+// 23..25  (z_k - z_ref)/z_k
+// 26      flags (bit 0: front facing)
+// 27      z_ref
+// 28..29  pixel box, four int16: col0 col1 | row0 row1   (also kept in a compact array)
+struct FaceRec {
+    float p0x, p0y, p1x, p1y, p2x, p2y;
+    float e0x, e0y, e1x, e1y, e2x, e2y;
+    float il0, il1, il2, inv_det;
+    float bx0, bx1, by0, by1;
+    float iz0, iz1, iz2;
+    float q0, q1, q2;
+    int flags;
+    float zref;
+};
+
+__device__ inline FaceRec load_rec(const float4 *r)
+{
+    const float4 a = r[0], b = r[1], c = r[2], d = r[3], e = r[4], f = r[5], g = r[6];
+    FaceRec o;
+    o.p0x = a.x; o.p0y = a.y; o.p1x = a.z; o.p1y = a.w;
+    o.p2x = b.x; o.p2y = b.y; o.e0x = b.z; o.e0y = b.w;
+    o.e1x = c.x; o.e1y = c.y; o.e2x = c.z; o.e2y = c.w;
+    o.il0 = d.x; o.il1 = d.y; o.il2 = d.z; o.inv_det = d.w;
+    o.bx0 = e.x; o.bx1 = e.y; o.by0 = e.z; o.by1 = e.w;
+    o.iz0 = f.x; o.iz1 = f.y; o.iz2 = f.z; o.q0 = f.w;
+    o.q1 = g.x; o.q2 = g.y; o.flags = __float_as_int(g.z); o.zref = g.w;
+    return o;
+}
+
+__device__ inline float sat(float x) { return __builtin_amdgcn_fmed3f(x, 0.f, 1.f); }
+__device__ inline float ex2(float x) { return __builtin_amdgcn_exp2f(x); }
+__device__ inline float rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+
+// Pixel centre in normalised device coordinates; row 0 is the top of the image.
+__device__ inline void pixel_centre(int col, int row, int S, float &xp, float &yp)
+{
+    const float fs = (float)S;
+    xp = (float)(2 * col + 1 - S) / fs;
+    yp = (float)(2 * (S - 1 - row) + 1 - S) / fs;
+}
+
+// Everything about one (pixel, face) pair that does not depend on colours.
+struct PairGeom {
+    float d2, t, dx, dy;          // squared distance, edge parameter, foot - pixel
+    float w0, w1, w2;             // barycentric coordinates of the pixel
+    bool k0, k1, k2;              // which edge is nearest (first wins ties)
+    bool inside, act;
+    float D, omD;                 // sigmoid fragment and 1 - D
+};
+
+__device__ inline PairGeom pair_geom(const FaceRec &r, float xp, float yp, const DevParams &P)
+{
+    PairGeom g;
+    const float a0x = r.p0x - xp, a0y = r.p0y - yp;
+    const float a1x = r.p1x - xp, a1y = r.p1y - yp;
+    const float a2x = r.p2x - xp, a2y = r.p2y - yp;
+    const float t0 = sat(-(a0x * r.e0x + a0y * r.e0y) * r.il0);
+    const float t1 = sat(-(a1x * r.e1x + a1y * r.e1y) * r.il1);
+    const float t2 = sat(-(a2x * r.e2x + a2y * r.e2y) * r.il2);
+    const float d0x = fmaf(t0, r.e0x, a0x), d0y = fmaf(t0, r.e0y, a0y);
+    const float d1x = fmaf(t1, r.e1x, a1x), d1y = fmaf(t1, r.e1y, a1y);
+    const float d2x = fmaf(t2, r.e2x, a2x), d2y = fmaf(t2, r.e2y, a2y);
+    const float dd0 = d0x * d0x + d0y * d0y;
+    const float dd1 = d1x * d1x + d1y * d1y;
+    const float dd2 = d2x * d2x + d2y * d2y;
+    // edge functions: cross(e_k, pixel - p_k); w of the vertex opposite to edge k
+    const float c0 = r.e0y * a0x - r.e0x * a0y;
+    const float c1 = r.e1y * a1x - r.e1x * a1y;
+    const float c2 = r.e2y * a2x - r.e2x * a2y;
+    g.w0 = c1 * r.inv_det;
+    g.w1 = c2 * r.inv_det;
+    g.w2 = c0 * r.inv_det;
+    g.k0 = (dd0 <= dd1) && (dd0 <= dd2);
+    g.k1 = !g.k0 && (dd1 <= dd2);
+    g.k2 = !g.k0 && !g.k1;
+    g.d2 = g.k0 ? dd0 : (g.k1 ? dd1 : dd2);
+    g.t = g.k0 ? t0 : (g.k1 ? t1 : t2);
+    g.dx = g.k0 ? d0x : (g.k1 ? d1x : d2x);
+    g.dy = g.k0 ? d0y : (g.k1 ? d1y : d2y);
+    g.inside = (g.w0 > 0.f) && (g.w1 > 0.f) && (g.w2 > 0.f);
+    const bool in_box = !(xp > r.bx1 || xp < r.bx0 || yp > r.by1 || yp < r.by0);
+    g.act = in_box && (g.inside || g.d2 < P.threshold);
+    // exp(-x) with x = +-d2/sigma; D = 1/(1+exp(-x)); 1-D = exp(-x) D (no cancellation)
+    const float e = ex2((g.inside ? g.d2 : -g.d2) * P.neg_l2e_over_sigma);
+    const float D = rcp(1.f + e);
+    g.D = g.act ? D : 0.f;
+    g.omD = g.act ? e * D : 1.f;
+    return g;
+}
+
+// Depth and normalised clamped barycentrics of a pair.
+struct PairDepth {
+    float n0, n1, n2, rs;         // clamp(w) / sum, 1 / sum
+    float u, zp, zn;              // zp - z_ref, zp, -(zp - z_ref)/(far-near)
+    bool contrib;
+};
+
+__device__ inline PairDepth pair_depth(const FaceRec &r, const PairGeom &g, const DevParams &P)
+{
+    PairDepth d;
+    const float wc0 = sat(g.w0), wc1 = sat(g.w1), wc2 = sat(g.w2);
+    const float num = wc0 * r.q0 + wc1 * r.q1 + wc2 * r.q2;
+    const float den = wc0 * r.iz0 + wc1 * r.iz1 + wc2 * r.iz2;
+    d.u = num * rcp(den);
+    d.zp = r.zref + d.u;
+    d.rs = rcp(wc0 + wc1 + wc2);
+    d.n0 = wc0 * d.rs;
+    d.n1 = wc1 * d.rs;
+    d.n2 = wc2 * d.rs;
+    d.zn = -d.u * P.inv_range;
+    d.contrib = g.act && (d.zp >= P.near_plane) && (d.zp <= P.far_plane) &&
+                (P.double_side || (r.flags & 1));
+    return d;
+}
+
+__device__ inline int texel_index(float n0, float n1, int R)
+{
+    const float fx = n0 * (float)R, fy = n1 * (float)R;
+    const int wx = min((int)fx, R - 1), wy = min((int)fy, R - 1);
+    const bool lower = ((n0 + n1) * (float)R - (float)wx) - (float)wy <= 1.f;
+    return lower ? wy * R + wx : (R - 1 - wy) * R + (R - 1 - wx);
+}
+
+// ------------------------------------------------------------------------------------
+// setup
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void raster_setup_kernel(
+    DevParams P, const float *__restrict__ fv, float4 *__restrict__ rec, uint2 *__restrict__ pbox)
+{
+    const int gid = blockIdx.x * kThreads + threadIdx.x;
+    if (gid >= P.B * P.F) return;
+    const int b = gid / P.F;
+    const float *v = fv + (size_t)gid * 9;
+    const float x0 = v[0], y0 = v[1], z0 = v[2];
+    const float x1 = v[3], y1 = v[4], z1 = v[5];
+    const float x2 = v[6], y2 = v[7], z2 = v[8];
+    const float zref = fv[(size_t)b * P.F * 9 + 2];
+
+    const float e0x = x1 - x0, e0y = y1 - y0;
+    const float e1x = x2 - x1, e1y = y2 - y1;
+    const float e2x = x0 - x2, e2y = y0 - y2;
+    const float l0 = e0x * e0x + e0y * e0y, l1 = e1x * e1x + e1y * e1y, l2 = e2x * e2x + e2y * e2y;
+    const float raw_det = e0x * (y2 - y0) - e0y * (x2 - x0);
+    const float det = raw_det > 0.f ? fmaxf(raw_det, 1e-10f) : fminf(raw_det, -1e-10f);
+    const float bx0 = fminf(x0, fminf(x1, x2)) - P.margin, bx1 = fmaxf(x0, fmaxf(x1, x2)) + P.margin;
+    const float by0 = fminf(y0, fminf(y1, y2)) - P.margin, by1 = fmaxf(y0, fmaxf(y1, y2)) + P.margin;
+
+    // pixel box: every pixel whose centre can pass the float cull test, widened by one
+    const float fs = (float)P.S, hi = fs;
+    const float cx0 = floorf(fminf(fmaxf((fs * bx0 + fs - 1.f) * 0.5f, -2.f), hi)) - 1.f;
+    const float cx1 = ceilf(fminf(fmaxf((fs * bx1 + fs - 1.f) * 0.5f, -2.f), hi)) + 1.f;
+    const float cy0 = floorf(fminf(fmaxf((fs * by0 + fs - 1.f) * 0.5f, -2.f), hi)) - 1.f;
+    const float cy1 = ceilf(fminf(fmaxf((fs * by1 + fs - 1.f) * 0.5f, -2.f), hi)) + 1.f;
+    int col0 = max((int)cx0, 0), col1 = min((int)cx1, P.S - 1);
+    int yi0 = max((int)cy0, 0), yi1 = min((int)cy1, P.S - 1);
+    int row0 = P.S - 1 - yi1, row1 = P.S - 1 - yi0;
+    const bool finite = (bx0 == bx0) && (bx1 == bx1) && (by0 == by0) && (by1 == by1);
+    if (!finite || col0 > col1 || row0 > row1) {
+        col0 = 32767; col1 = -1; row0 = 32767; row1 = -1;
+    }
+    const uint2 box = make_uint2((uint32_t)(col0 & 0xffff) | ((uint32_t)(col1 & 0xffff) << 16),
+                                 (uint32_t)(row0 & 0xffff) | ((uint32_t)(row1 & 0xffff) << 16));
+    const float iz0 = 1.f / z0, iz1 = 1.f / z1, iz2 = 1.f / z2;
+    float4 *r = rec + (size_t)gid * kRec4;
+    r[0] = make_float4(x0, y0, x1, y1);
+    r[1] = make_float4(x2, y2, e0x, e0y);
+    r[2] = make_float4(e1x, e1y, e2x, e2y);
+    r[3] = make_float4(l0 > 0.f ? 1.f / l0 : 0.f, l1 > 0.f ? 1.f / l1 : 0.f,
+                       l2 > 0.f ? 1.f / l2 : 0.f, 1.f / det);
+    r[4] = make_float4(bx0, bx1, by0, by1);
+    r[5] = make_float4(iz0, iz1, iz2, (z0 - zref) * iz0);
+    r[6] = make_float4((z1 - zref) * iz1, (z2 - zref) * iz2,
+                       __int_as_float(raw_det < 0.f ? 1 : 0), zref);
+    r[7] = make_float4(__uint_as_float(box.x), __uint_as_float(box.y), 0.f, 0.f);
+    pbox[gid] = box;
+}
+
+__device__ inline void unpack_box(uint2 b, int &col0, int &col1, int &row0, int &row1)
+{
+    col0 = (int)(short)(b.x & 0xffff);
+    col1 = (int)(short)(b.x >> 16);
+    row0 = (int)(short)(b.y & 0xffff);
+    row1 = (int)(short)(b.y >> 16);
+}
+
+// ------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(kThreads) void raster_forward_kernel(
+    DevParams P, const float4 *__restrict__ rec, const uint2 *__restrict__ pbox,
+    const float *__restrict__ tex, float *__restrict__ rgba, float *__restrict__ saved)
+{
+    __shared__ float4 s_rec[kListCap * kRec4];
+    __shared__ int s_ids[kListCap];
+    __shared__ int s_wtot[4];
+
+    const int b = blockIdx.z;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int S = P.S, F = P.F;
+    const int tile_c0 = blockIdx.x * kTile, tile_r0 = blockIdx.y * kTile;
+    // lane -> pixel of the wave's 8x8 block; lanes 4q..4q+3 form the 2x2 quad q
+    const int quad = lane >> 2, sub = lane & 3;
+    const int blk_c0 = tile_c0 + (wave & 1) * 8, blk_r0 = tile_r0 + (wave >> 1) * 8;
+    const int col = blk_c0 + (quad & 3) * 2 + (sub & 1);
+    const int row = blk_r0 + (quad >> 2) * 2 + (sub >> 1);
+    float xp, yp;
+    pixel_centre(col, row, S, xp, yp);
+    // NDC extent of the pixel centres of this wave's block
+    float bxa, bxb, bya, byb;
+    pixel_centre(blk_c0, blk_r0 + 7, S, bxa, bya);
+    pixel_centre(blk_c0 + 7, blk_r0, S, bxb, byb);
+
+    const float4 *rec_b = rec + (size_t)b * F * kRec4;
+    const uint2 *pbox_b = pbox + (size_t)b * F;
+    const float zref = ((const float *)rec_b)[27];
+    const float c0shift = (P.far_plane - zref) * P.inv_range;
+
+    float A = 1.f;                              // prod (1 - D)
+    float m = P.eps - c0shift;                  // running softmax maximum, shifted by c0shift
+    float ssum = P.ssum0;
+    float C0 = P.bg0 * ssum, C1 = P.bg1 * ssum, C2 = P.bg2 * ssum;
+
+    auto process_list = [&](int n) {
+        for (int i = threadIdx.x; i < n * kRec4; i += kThreads)
+            s_rec[i] = rec_b[(size_t)s_ids[i / kRec4] * kRec4 + (i % kRec4)];
+        __syncthreads();
+        for (int j0 = 0; j0 < n; j0 += 64) {
+            const int j = j0 + lane;
+            bool hit = false;
+            if (j < n) {
+                const float4 bb = s_rec[j * kRec4 + 4];
+                hit = !(bxa > bb.y || bxb < bb.x || bya > bb.w || byb < bb.z);
+            }
+            unsigned long long mask = __ballot(hit);
+            while (mask) {
+                const int jj = j0 + __builtin_ctzll(mask);
+                mask &= mask - 1;
+                const FaceRec r = load_rec(&s_rec[jj * kRec4]);
+                const PairGeom g = pair_geom(r, xp, yp, P);
+                A *= g.omD;
+                if (MODE != SV3D_TEX_NONE) {
+                    const PairDepth d = pair_depth(r, g, P);
+                    float k0 = 0.f, k1 = 0.f, k2 = 0.f;
+                    if (d.contrib) {
+                        const int fid = s_ids[jj];
+                        if (MODE == SV3D_TEX_SURFACE) {
+                            const int Ts = P.R * P.R;
+                            const float *tp = tex + (((size_t)b * F + fid) * Ts +
+                                                     texel_index(d.n0, d.n1, P.R)) * 3;
+                            k0 = tp[0]; k1 = tp[1]; k2 = tp[2];
+                        } else {
+                            const float *tp = tex + ((size_t)b * F + fid) * 9;
+                            k0 = d.n0 * tp[0] + d.n1 * tp[3] + d.n2 * tp[6];
+                            k1 = d.n0 * tp[1] + d.n1 * tp[4] + d.n2 * tp[7];
+                            k2 = d.n0 * tp[2] + d.n1 * tp[5] + d.n2 * tp[8];
+                        }
+                    }
+                    const float mnew = d.contrib ? fmaxf(m, d.zn) : m;
+                    const float rs = ex2((m - mnew) * P.l2e_over_gamma);
+                    const float ez = d.contrib ? ex2((d.zn - mnew) * P.l2e_over_gamma) : 0.f;
+                    const float wgt = ez * g.D;
+                    ssum = fmaf(rs, ssum, wgt);
+                    C0 = fmaf(rs, C0, wgt * k0);
+                    C1 = fmaf(rs, C1, wgt * k1);
+                    C2 = fmaf(rs, C2, wgt * k2);
+                    m = mnew;
+                }
+            }
+        }
+        __syncthreads();
+    };
+
+    // Ordered compaction of the faces whose pixel box touches this tile.
+    const int tc1 = tile_c0 + kTile - 1, tr1 = tile_r0 + kTile - 1;
+    int count = 0;
+    for (int base = 0; base < F; base += kThreads) {
+        const int f = base + (int)threadIdx.x;
+        bool hit = false;
+        if (f < F) {
+            int c0, c1, r0, r1;
+            unpack_box(pbox_b[f], c0, c1, r0, r1);
+            hit = !(c1 < tile_c0 || c0 > tc1 || r1 < tile_r0 || r0 > tr1);
+        }
+        const unsigned long long mask = __ballot(hit);
+        const int prefix = __popcll(mask & ((1ull << lane) - 1ull));
+        if (lane == 0) s_wtot[wave] = __popcll(mask);
+        __syncthreads();
+        const int t0 = s_wtot[0], t1 = s_wtot[1], t2 = s_wtot[2], t3 = s_wtot[3];
+        const int total = t0 + t1 + t2 + t3;
+        if (count + total > kListCap) {        // block-uniform
+            process_list(count);
+            count = 0;
+        }
+        const int woff = (wave > 0 ? t0 : 0) + (wave > 1 ? t1 : 0) + (wave > 2 ? t2 : 0);
+        if (hit) s_ids[count + woff + prefix] = f;
+        count += total;
+        __syncthreads();
+    }
+    if (count > 0) process_list(count);
+
+    // epilogue
+    float o0, o1, o2;
+    if (MODE != SV3D_TEX_NONE) {
+        const float is = 1.f / ssum;
+        o0 = C0 * is; o1 = C1 * is; o2 = C2 * is;
+    } else {
+        o0 = P.bg0; o1 = P.bg1; o2 = P.bg2;
+    }
+    float o3 = 1.f - A;
+    const bool inimg = col < S && row < S;
+    if (inimg) {
+        const size_t pix = ((size_t)b * S + row) * S + col;
+        if (MODE == SV3D_TEX_NONE) {
+            saved[pix] = A;
+        } else {
+            float2 *sp = (float2 *)(saved + pix * 6);
+            sp[0] = make_float2(A, ssum);
+            sp[1] = make_float2(m, o0);
+            sp[2] = make_float2(o1, o2);
+        }
+    }
+    if (P.aa == 2) {
+        if (!inimg) { o0 = o1 = o2 = o3 = 0.f; }
+        o0 += __shfl_xor(o0, 1); o1 += __shfl_xor(o1, 1); o2 += __shfl_xor(o2, 1); o3 += __shfl_xor(o3, 1);
+        o0 += __shfl_xor(o0, 2); o1 += __shfl_xor(o1, 2); o2 += __shfl_xor(o2, 2); o3 += __shfl_xor(o3, 2);
+        const int H = S >> 1;
+        if (sub == 0 && inimg) {
+            const size_t o = ((size_t)b * 4 * H + (row >> 1)) * H + (col >> 1);
+            const size_t plane = (size_t)H * H;
+            rgba[o] = 0.25f * o0;
+            rgba[o + plane] = 0.25f * o1;
+            rgba[o + 2 * plane] = 0.25f * o2;
+            rgba[o + 3 * plane] = 0.25f * o3;
+        }
+    } else if (inimg) {
+        const size_t o = ((size_t)b * 4 * S + row) * S + col;
+        const size_t plane = (size_t)S * S;
+        rgba[o] = o0;
+        rgba[o + plane] = o1;
+        rgba[o + 2 * plane] = o2;
+        rgba[o + 3 * plane] = o3;
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// backward
+// ------------------------------------------------------------------------------------
+// Per raster pixel, fold the incoming gradient with the saved aggregates:
+//   NONE    : { g_alpha * A }
+//   colours : { g_alpha * A, g_k / ssum (k=0..2), sum_k g_k rgb_k / ssum, m }
+template <int MODE>
+__global__ __launch_bounds__(kThreads) void raster_prep_kernel(
+    DevParams P, const float *__restrict__ saved, const float *__restrict__ grad_rgba,
+    float *__restrict__ prep)
+{
+    const size_t idx = (size_t)blockIdx.x * kThreads + threadIdx.x;
+    const size_t npix = (size_t)P.S * P.S;
+    if (idx >= (size_t)P.B * npix) return;
+    const int b = (int)(idx / npix);
+    const int rem = (int)(idx - (size_t)b * npix);
+    const int row = rem / P.S, col = rem - row * P.S;
+    const int H = P.S / P.aa;
+    const float scale = P.aa == 2 ? 0.25f : 1.f;
+    const size_t plane = (size_t)H * H;
+    const size_t g = ((size_t)b * 4 * H + row / P.aa) * H + col / P.aa;
+    const float ga = grad_rgba[g + 3 * plane] * scale;
+    if (MODE == SV3D_TEX_NONE) {
+        prep[idx] = ga * saved[idx];
+    } else {
+        const float g0 = grad_rgba[g] * scale, g1 = grad_rgba[g + plane] * scale,
+                    g2 = grad_rgba[g + 2 * plane] * scale;
+        const float2 *sp = (const float2 *)(saved + idx * 6);
+        const float2 s0 = sp[0], s1 = sp[1], s2 = sp[2];      // (A, ssum) (m, r) (g, b)
+        const float is = 1.f / s0.y;
+        float2 *pp = (float2 *)(prep + idx * 6);
+        pp[0] = make_float2(ga * s0.x, g0 * is);
+        pp[1] = make_float2(g1 * is, g2 * is);
+        pp[2] = make_float2((g0 * s1.y + g1 * s2.x + g2 * s2.y) * is, s1.x);
+    }
+}
+
+template <int CTRL, int ROW_MASK>
+__device__ inline float dpp_add(float v)
+{
+    const int moved = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, false);
+    return v + __int_as_float(moved);
+}
+
+// Sum over the 64 lanes with a fixed tree; the result is returned in every lane.
+__device__ inline float wave_sum(float v)
+{
+    v = dpp_add<0xB1, 0xf>(v);      // quad_perm [1,0,3,2]
+    v = dpp_add<0x4E, 0xf>(v);      // quad_perm [2,3,0,1]
+    v = dpp_add<0x141, 0xf>(v);     // row_half_mirror
+    v = dpp_add<0x140, 0xf>(v);     // row_mirror: every lane of a row holds the row sum
+    const float a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+    const float b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+    const float c = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
+    const float d = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+    return (a + b) + (c + d);
+}
+
+template <int MODE>
+__global__ __launch_bounds__(kThreads) void raster_backward_kernel(
+    DevParams P, const float4 *__restrict__ rec, const uint2 *__restrict__ pbox,
+    const float *__restrict__ tex, const float *__restrict__ prep,
+    float *__restrict__ gfv, float *__restrict__ gtex)
+{
+    extern __shared__ float s_dyn[];            // SURFACE: 4 x (R*R*3) texel accumulators
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int gf = blockIdx.x * 4 + wave;       // global face index b*F + f
+    if (gf >= P.B * P.F) return;                // whole wave; no block-level barrier is used
+    const int b = gf / P.F;
+    const int S = P.S;
+    const FaceRec r = load_rec(rec + (size_t)gf * kRec4);
+    int col0, col1, row0, row1;
+    unpack_box(pbox[gf], col0, col1, row0, row1);
+    const int bw = col1 - col0 + 1, bh = row1 - row0 + 1;
+    const int npix = (bw > 0 && bh > 0) ? bw * bh : 0;
+    const float inv_bw = bw > 0 ? 1.f / (float)bw : 0.f;
+
+    const int Ts = P.R * P.R;
+    float *s_tex = s_dyn + wave * Ts * 3;
+    float tv[9];
+    if (MODE == SV3D_TEX_SURFACE) {
+        for (int i = lane; i < Ts * 3; i += 64) s_tex[i] = 0.f;
+    } else if (MODE == SV3D_TEX_VERTEX) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) tv[i] = tex[(size_t)gf * 9 + i];
+    }
+
+    float acc[9];
+    float tacc[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) { acc[i] = 0.f; tacc[i] = 0.f; }
+
+    for (int base = 0; base < npix; base += 64) {
+        const int idx = base + lane;
+        const bool valid = idx < npix;
+        int ry = (int)(((float)idx + 0.5f) * inv_bw);
+        int rx = idx - ry * bw;
+        if (rx < 0) { ry -= 1; rx += bw; }
+        if (rx >= bw) { ry += 1; rx -= bw; }
+        const int col = valid ? col0 + rx : col0;
+        const int row = valid ? row0 + ry : row0;
+        float xp, yp;
+        pixel_centre(col, row, S, xp, yp);
+        const size_t pix = ((size_t)b * S + row) * S + col;
+
+        PairGeom g = pair_geom(r, xp, yp, P);
+        const bool act = valid && g.act;
+        float P0;
+        float G0 = 0.f, G1 = 0.f, G2 = 0.f, Rr = 0.f, mfin = 0.f;
+        if (MODE == SV3D_TEX_NONE) {
+            P0 = prep[pix];
+        } else {
+            const float2 *pp = (const float2 *)(prep + pix * 6);
+            const float2 a0 = pp[0], a1 = pp[1], a2 = pp[2];
+            P0 = a0.x; G0 = a0.y; G1 = a1.x; G2 = a1.y; Rr = a2.x; mfin = a2.y;
+        }
+        float gx = act ? P0 * g.D : 0.f;        // dL/dx, x = +-d2/sigma, through alpha
+
+        if (MODE != SV3D_TEX_NONE) {
+            const PairDepth d = pair_depth(r, g, P);
+            const bool contrib = valid && d.contrib;
+            if (contrib) {
+                const float ez = ex2((d.zn - mfin) * P.l2e_over_gamma);
+                float k0, k1, k2;
+                int tid = 0;
+                if (MODE == SV3D_TEX_SURFACE) {
+                    tid = texel_index(d.n0, d.n1, P.R);
+                    const float *tp = tex + ((size_t)gf * Ts + tid) * 3;
+                    k0 = tp[0]; k1 = tp[1]; k2 = tp[2];
+                } else {
+                    k0 = d.n0 * tv[0] + d.n1 * tv[3] + d.n2 * tv[6];
+                    k1 = d.n0 * tv[1] + d.n1 * tv[4] + d.n2 * tv[7];
+                    k2 = d.n0 * tv[2] + d.n1 * tv[5] + d.n2 * tv[8];
+                }
+                const float S1 = G0 * k0 + G1 * k1 + G2 * k2 - Rr;
+                const float De = g.D * ez;
+                gx += De * g.omD * S1;                               // through D of the softmax weight
+                const float gz = -(De * S1) * P.inv_gamma * P.inv_range;   // dL/dzp
+                const float gc0 = G0 * De, gc1 = G1 * De, gc2 = G2 * De;   // dL/dcolour
+                const float zp2 = d.zp * d.zp;
+                acc[2] += gz * zp2 * d.n0 * r.iz0 * r.iz0;
+                acc[5] += gz * zp2 * d.n1 * r.iz1 * r.iz1;
+                acc[8] += gz * zp2 * d.n2 * r.iz2 * r.iz2;
+                float gn0 = -gz * zp2 * r.iz0, gn1 = -gz * zp2 * r.iz1, gn2 = -gz * zp2 * r.iz2;
+                if (MODE == SV3D_TEX_SURFACE) {
+                    if (gtex != nullptr) {
+                        atomicAdd(&s_tex[tid * 3 + 0], gc0);
+                        atomicAdd(&s_tex[tid * 3 + 1], gc1);
+                        atomicAdd(&s_tex[tid * 3 + 2], gc2);
+                    }
+                } else {
+                    tacc[0] += d.n0 * gc0; tacc[1] += d.n0 * gc1; tacc[2] += d.n0 * gc2;
+                    tacc[3] += d.n1 * gc0; tacc[4] += d.n1 * gc1; tacc[5] += d.n1 * gc2;
+                    tacc[6] += d.n2 * gc0; tacc[7] += d.n2 * gc1; tacc[8] += d.n2 * gc2;
+                    gn0 += gc0 * tv[0] + gc1 * tv[1] + gc2 * tv[2];
+                    gn1 += gc0 * tv[3] + gc1 * tv[4] + gc2 * tv[5];
+                    gn2 += gc0 * tv[6] + gc1 * tv[7] + gc2 * tv[8];
+                }
+                // through the normalisation n = clamp(w)/sum and the clamp
+                const float dotn = gn0 * d.n0 + gn1 * d.n1 + gn2 * d.n2;
+                const float gw0 = (g.w0 > 0.f && g.w0 < 1.f) ? (gn0 - dotn) * d.rs : 0.f;
+                const float gw1 = (g.w1 > 0.f && g.w1 < 1.f) ? (gn1 - dotn) * d.rs : 0.f;
+                const float gw2 = (g.w2 > 0.f && g.w2 < 1.f) ? (gn2 - dotn) * d.rs : 0.f;
+                // grad_w_j = (-e_{j+1}.y, e_{j+1}.x) / det; moving vertex i shifts the pixel's
+                // barycentrics like moving the pixel by -w_i
+                const float Vx = -r.inv_det * (gw0 * r.e1y + gw1 * r.e2y + gw2 * r.e0y);
+                const float Vy = r.inv_det * (gw0 * r.e1x + gw1 * r.e2x + gw2 * r.e0x);
+                acc[0] -= g.w0 * Vx; acc[1] -= g.w0 * Vy;
+                acc[3] -= g.w1 * Vx; acc[4] -= g.w1 * Vy;
+                acc[6] -= g.w2 * Vx; acc[7] -= g.w2 * Vy;
+            }
+        }
+        // through the distance: d2 = |foot - pixel|^2, foot = (1-t) p_k + t p_{k+1}
+        const float gd = 2.f * gx * (g.inside ? P.inv_sigma : -P.inv_sigma);
+        const float cA = gd * (1.f - g.t), cB = gd * g.t;
+        const float f0 = g.k0 ? cA : (g.k2 ? cB : 0.f);
+        const float f1 = g.k1 ? cA : (g.k0 ? cB : 0.f);
+        const float f2 = g.k2 ? cA : (g.k1 ? cB : 0.f);
+        acc[0] = fmaf(f0, g.dx, acc[0]); acc[1] = fmaf(f0, g.dy, acc[1]);
+        acc[3] = fmaf(f1, g.dx, acc[3]); acc[4] = fmaf(f1, g.dy, acc[4]);
+        acc[6] = fmaf(f2, g.dx, acc[6]); acc[7] = fmaf(f2, g.dy, acc[7]);
+    }
+
+    float tot[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) tot[i] = wave_sum(acc[i]);
+    if (lane == 0) {
+        float *o = gfv + (size_t)gf * 9;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) o[i] = tot[i];
+    }
+    if (gtex != nullptr) {
+        if (MODE == SV3D_TEX_SURFACE) {
+            for (int i = lane; i < Ts * 3; i += 64) gtex[(size_t)gf * Ts * 3 + i] = s_tex[i];
+        } else if (MODE == SV3D_TEX_VERTEX) {
+            float tt[9];
+#pragma unroll
+            for (int i = 0; i < 9; ++i) tt[i] = wave_sum(tacc[i]);
+            if (lane == 0) {
+#pragma unroll
+                for (int i = 0; i < 9; ++i) gtex[(size_t)gf * 9 + i] = tt[i];
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------
+int make_dev_params(const sv3d_raster_params *p, DevParams &d)
+{
+    if (!p) return SV3D_ERR_INVALID_ARG;
+    if (p->batch <= 0 || p->num_faces <= 0 || p->raster_size <= 0) return SV3D_ERR_INVALID_ARG;
+    if (p->aa != 1 && p->aa != 2) return SV3D_ERR_INVALID_ARG;
+    if (p->aa == 2 && (p->raster_size & 1)) return SV3D_ERR_INVALID_ARG;
+    if (p->texture_mode < SV3D_TEX_NONE || p->texture_mode > SV3D_TEX_VERTEX) return SV3D_ERR_INVALID_ARG;
+    if (p->texture_mode == SV3D_TEX_SURFACE && p->texture_res <= 0) return SV3D_ERR_INVALID_ARG;
+    if (!(p->sigma > 0.f) || !(p->gamma > 0.f) || !(p->dist_eps > 0.f) || !(p->dist_eps < 1.f))
+        return SV3D_ERR_INVALID_ARG;
+    if (!(p->far_plane > p->near_plane)) return SV3D_ERR_INVALID_ARG;
+    if (p->raster_size > 16384 || p->batch > 65535) return SV3D_ERR_UNSUPPORTED;
+    if ((long)p->batch * p->num_faces > 0x7fffffffL / 4) return SV3D_ERR_UNSUPPORTED;
+    if (p->texture_mode == SV3D_TEX_SURFACE && p->texture_res > 36) return SV3D_ERR_UNSUPPORTED;
+    const double l2e = 1.4426950408889634;
+    d.B = p->batch; d.F = p->num_faces; d.S = p->raster_size; d.aa = p->aa;
+    d.mode = p->texture_mode; d.R = p->texture_mode == SV3D_TEX_SURFACE ? p->texture_res : 1;
+    d.double_side = p->double_side;
+    d.bg0 = p->background[0]; d.bg1 = p->background[1]; d.bg2 = p->background[2];
+    d.near_plane = p->near_plane; d.far_plane = p->far_plane; d.eps = p->eps;
+    d.neg_l2e_over_sigma = (float)(-l2e / (double)p->sigma);
+    d.inv_sigma = (float)(1.0 / (double)p->sigma);
+    const double thr = log(1.0 / (double)p->dist_eps - 1.0) * (double)p->sigma;
+    d.threshold = (float)thr;
+    d.margin = (float)sqrt(thr > 0.0 ? thr : 0.0);
+    d.l2e_over_gamma = (float)(l2e / (double)p->gamma);
+    d.inv_gamma = (float)(1.0 / (double)p->gamma);
+    d.inv_range = (float)(1.0 / ((double)p->far_plane - (double)p->near_plane));
+    d.ssum0 = (float)exp((double)p->eps / (double)p->gamma);
+    return SV3D_OK;
+}
+
+inline size_t rec_floats(const DevParams &d) { return (size_t)d.B * d.F * kRec; }
+inline int saved_per_pixel(const DevParams &d) { return d.mode == SV3D_TEX_NONE ? 1 : 6; }
+
+inline int launch_status()
+{
+    return hipGetLastError() == hipSuccess ? SV3D_OK : SV3D_ERR_LAUNCH;
+}
+
+}  // namespace
+
+extern "C" int sv3d_raster_sizes(const sv3d_raster_params *p, size_t *face_rec_bytes,
+                                 size_t *pixel_saved_bytes, size_t *backward_ws_bytes)
+{
+    DevParams d;
+    const int st = make_dev_params(p, d);
+    if (st != SV3D_OK) return st;
+    const size_t pix = (size_t)d.B * d.S * d.S * saved_per_pixel(d) * sizeof(float);
+    if (face_rec_bytes) *face_rec_bytes = rec_floats(d) * sizeof(float) + (size_t)d.B * d.F * sizeof(uint2);
+    if (pixel_saved_bytes) *pixel_saved_bytes = pix;
+    if (backward_ws_bytes) *backward_ws_bytes = pix;
+    return SV3D_OK;
+}
+
+extern "C" int sv3d_raster_forward(const sv3d_raster_params *p, const float *face_vertices,
+                                   const float *textures, float *rgba_out, void *face_rec,
+                                   void *pixel_saved, void *stream)
+{
+    DevParams d;
+    const int st = make_dev_params(p, d);
+    if (st != SV3D_OK) return st;
+    if (!face_vertices || !rgba_out || !face_rec || !pixel_saved) return SV3D_ERR_INVALID_ARG;
+    if (d.mode != SV3D_TEX_NONE && !textures) return SV3D_ERR_INVALID_ARG;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    float4 *rec = static_cast<float4 *>(face_rec);
+    uint2 *pbox = reinterpret_cast<uint2 *>(static_cast<float *>(face_rec) + rec_floats(d));
+    const int nf = d.B * d.F;
+    hipLaunchKernelGGL(raster_setup_kernel, dim3((nf + kThreads - 1) / kThreads), dim3(kThreads), 0, s,
+                       d, face_vertices, rec, pbox);
+    const int tiles = (d.S + kTile - 1) / kTile;
+    dim3 grid(tiles, tiles, d.B), block(kThreads);
+    float *saved = static_cast<float *>(pixel_saved);
+    if (d.mode == SV3D_TEX_NONE)
+        hipLaunchKernelGGL(raster_forward_kernel<SV3D_TEX_NONE>, grid, block, 0, s, d, rec, pbox, textures, rgba_out, saved);
+    else if (d.mode == SV3D_TEX_SURFACE)
+        hipLaunchKernelGGL(raster_forward_kernel<SV3D_TEX_SURFACE>, grid, block, 0, s, d, rec, pbox, textures, rgba_out, saved);
+    else
+        hipLaunchKernelGGL(raster_forward_kernel<SV3D_TEX_VERTEX>, grid, block, 0, s, d, rec, pbox, textures, rgba_out, saved);
+    return launch_status();
+}
+
+extern "C" int sv3d_raster_backward(const sv3d_raster_params *p, const float *textures,
+                                    const void *face_rec, const void *pixel_saved,
+                                    const float *grad_rgba, float *grad_face_vertices,
+                                    float *grad_textures, void *workspace, size_t workspace_bytes,
+                                    void *stream)
+{
+    DevParams d;
+    const int st = make_dev_params(p, d);
+    if (st != SV3D_OK) return st;
+    if (!face_rec || !pixel_saved || !grad_rgba || !grad_face_vertices || !workspace)
+        return SV3D_ERR_INVALID_ARG;
+    if (d.mode != SV3D_TEX_NONE && !textures) return SV3D_ERR_INVALID_ARG;
+    const size_t need = (size_t)d.B * d.S * d.S * saved_per_pixel(d) * sizeof(float);
+    if (workspace_bytes < need) return SV3D_ERR_WORKSPACE;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const float4 *rec = static_cast<const float4 *>(face_rec);
+    const uint2 *pbox = reinterpret_cast<const uint2 *>(static_cast<const float *>(face_rec) + rec_floats(d));
+    const float *saved = static_cast<const float *>(pixel_saved);
+    float *prep = static_cast<float *>(workspace);
+    const size_t npix = (size_t)d.B * d.S * d.S;
+    const dim3 pgrid((unsigned)((npix + kThreads - 1) / kThreads)), block(kThreads);
+    const dim3 fgrid((d.B * d.F + 3) / 4);
+    if (d.mode == SV3D_TEX_NONE) {
+        hipLaunchKernelGGL(raster_prep_kernel<SV3D_TEX_NONE>, pgrid, block, 0, s, d, saved, grad_rgba, prep);
+        hipLaunchKernelGGL(raster_backward_kernel<SV3D_TEX_NONE>, fgrid, block, 0, s, d, rec, pbox,
+                           textures, prep, grad_face_vertices, (float *)nullptr);
+    } else if (d.mode == SV3D_TEX_SURFACE) {
+        const size_t lds = (size_t)4 * d.R * d.R * 3 * sizeof(float);
+        hipLaunchKernelGGL(raster_prep_kernel<SV3D_TEX_SURFACE>, pgrid, block, 0, s, d, saved, grad_rgba, prep);
+        hipLaunchKernelGGL(raster_backward_kernel<SV3D_TEX_SURFACE>, fgrid, block, lds, s, d, rec, pbox,
+                           textures, prep, grad_face_vertices, grad_textures);
+    } else {
+        hipLaunchKernelGGL(raster_prep_kernel<SV3D_TEX_VERTEX>, pgrid, block, 0, s, d, saved, grad_rgba, prep);
+        hipLaunchKernelGGL(raster_backward_kernel<SV3D_TEX_VERTEX>, fgrid, block, 0, s, d, rec, pbox,
+                           textures, prep, grad_face_vertices, grad_textures);
+    }
+    return launch_status();
+}

@@ -1,0 +1,8 @@
+"""sv3d: MI355X-native hot path (soft rasterizer + Chamfer NN) behind a C ABI.
+
+`sv3d._lib` binds libsv3d_hip.so, `sv3d.ops` exposes it as PyTorch-ROCm custom ops.
+"""
+from . import _lib
+from .ops import chamfer_nn, face_gather, soft_rasterize
+
+__all__ = ["_lib", "chamfer_nn", "face_gather", "soft_rasterize"]

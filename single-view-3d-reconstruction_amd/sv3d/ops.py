@@ -1,0 +1,320 @@
+"""PyTorch-ROCm custom ops over the libsv3d_hip.so C ABI.
+
+Ops (namespace `sv3d`), all CUDA(HIP)-only -- a CPU tensor raises, there is no fallback:
+
+  soft_rasterize / soft_rasterize_backward   the third-party `soft_rasterize` the reference
+                                             reaches from nnutils/softras.py:64,75,77
+  chamfer_nn / chamfer_nn_backward           the third-party ChamferDistance called at
+                                             nnutils/loss_utils.py:85-86
+  face_gather / face_scatter                 sr.Mesh's `vertices[faces]` + affine pre-stage
+
+torch is used for device memory, streams and autograd plumbing only.
+"""
+import ctypes
+from typing import List, Optional, Tuple
+
+import torch
+from torch import Tensor
+
+from . import _lib as L
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None and t.numel() > 0 else None
+
+
+def _stream(t):
+    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def _f32c(t):
+    return t.detach().to(torch.float32).contiguous()
+
+
+def _params(fv, raster_size, aa, texture_mode, texture_res, double_side, background,
+            near, far, eps, sigma, dist_eps, gamma):
+    return L.make_params(fv.shape[0], fv.shape[1], raster_size, aa, texture_mode, texture_res,
+                         double_side, background, near, far, eps, sigma, dist_eps, gamma)
+
+
+def _check_raster_inputs(fv, tex, texture_mode, texture_res):
+    if fv.dim() != 4 or fv.shape[2:] != (3, 3):
+        raise ValueError("face_vertices must be [B,F,3,3], got %s" % (tuple(fv.shape),))
+    if texture_mode == L.SV3D_TEX_NONE:
+        return
+    if tex is None:
+        raise ValueError("textures required for texture_mode %d" % texture_mode)
+    want = (fv.shape[0], fv.shape[1], texture_res * texture_res, 3) \
+        if texture_mode == L.SV3D_TEX_SURFACE else (fv.shape[0], fv.shape[1], 3, 3)
+    if tuple(tex.shape) != want:
+        raise ValueError("textures must be %s, got %s" % (want, tuple(tex.shape)))
+
+
+# ---- soft rasterizer -----------------------------------------------------------------
+@torch.library.custom_op("sv3d::soft_rasterize", mutates_args=(), device_types="cuda")
+def soft_rasterize_op(face_vertices: Tensor, textures: Optional[Tensor], raster_size: int, aa: int,
+                      texture_mode: int, texture_res: int, double_side: bool,
+                      background: List[float], near: float, far: float, eps: float, sigma: float,
+                      dist_eps: float, gamma: float) -> Tuple[Tensor, Tensor, Tensor]:
+    _check_raster_inputs(face_vertices, textures, texture_mode, texture_res)
+    fv = _f32c(face_vertices)
+    tex = _f32c(textures) if texture_mode != L.SV3D_TEX_NONE else None
+    p = _params(fv, raster_size, aa, texture_mode, texture_res, double_side, background,
+                near, far, eps, sigma, dist_eps, gamma)
+    rec_b, saved_b, _ = L.raster_sizes(p)
+    H = raster_size // aa
+    with torch.cuda.device(fv.device):
+        rgba = torch.empty((fv.shape[0], 4, H, H), dtype=torch.float32, device=fv.device)
+        rec = torch.empty(rec_b // 4, dtype=torch.float32, device=fv.device)
+        saved = torch.empty(saved_b // 4, dtype=torch.float32, device=fv.device)
+        L.check(L.lib().sv3d_raster_forward(ctypes.byref(p), _ptr(fv), _ptr(tex), _ptr(rgba),
+                                            _ptr(rec), _ptr(saved), _stream(fv)),
+                "sv3d_raster_forward")
+    return rgba, rec, saved
+
+
+@soft_rasterize_op.register_fake
+def _(face_vertices, textures, raster_size, aa, texture_mode, texture_res, double_side,
+      background, near, far, eps, sigma, dist_eps, gamma):
+    B, F = face_vertices.shape[0], face_vertices.shape[1]
+    H = raster_size // aa
+    per = 1 if texture_mode == L.SV3D_TEX_NONE else 6
+    return (face_vertices.new_empty((B, 4, H, H), dtype=torch.float32),
+            face_vertices.new_empty((B * F * 34,), dtype=torch.float32),
+            face_vertices.new_empty((B * raster_size * raster_size * per,), dtype=torch.float32))
+
+
+@torch.library.custom_op("sv3d::soft_rasterize_backward", mutates_args=(), device_types="cuda")
+def soft_rasterize_backward_op(grad_rgba: Tensor, textures: Optional[Tensor], face_rec: Tensor,
+                               pixel_saved: Tensor, batch: int, num_faces: int, raster_size: int,
+                               aa: int, texture_mode: int, texture_res: int, double_side: bool,
+                               background: List[float], near: float, far: float, eps: float,
+                               sigma: float, dist_eps: float, gamma: float,
+                               need_textures: bool) -> Tuple[Tensor, Tensor]:
+    g = _f32c(grad_rgba)
+    tex = _f32c(textures) if texture_mode != L.SV3D_TEX_NONE else None
+    p = L.make_params(batch, num_faces, raster_size, aa, texture_mode, texture_res, double_side,
+                      background, near, far, eps, sigma, dist_eps, gamma)
+    _, _, ws_b = L.raster_sizes(p)
+    with torch.cuda.device(g.device):
+        gfv = torch.empty((batch, num_faces, 3, 3), dtype=torch.float32, device=g.device)
+        gtex = torch.empty_like(tex) if (tex is not None and need_textures) else \
+            torch.empty(0, dtype=torch.float32, device=g.device)
+        ws = torch.empty(ws_b // 4, dtype=torch.float32, device=g.device)
+        L.check(L.lib().sv3d_raster_backward(ctypes.byref(p), _ptr(tex), _ptr(face_rec),
+                                             _ptr(pixel_saved), _ptr(g), _ptr(gfv), _ptr(gtex),
+                                             _ptr(ws), ctypes.c_size_t(ws_b), _stream(g)),
+                "sv3d_raster_backward")
+    return gfv, gtex
+
+
+@soft_rasterize_backward_op.register_fake
+def _(grad_rgba, textures, face_rec, pixel_saved, batch, num_faces, raster_size, aa, texture_mode,
+      texture_res, double_side, background, near, far, eps, sigma, dist_eps, gamma, need_textures):
+    gfv = grad_rgba.new_empty((batch, num_faces, 3, 3), dtype=torch.float32)
+    gtex = torch.empty_like(textures, dtype=torch.float32) if (textures is not None and need_textures) \
+        else grad_rgba.new_empty((0,), dtype=torch.float32)
+    return gfv, gtex
+
+
+def _raster_setup_context(ctx, inputs, output):
+    fv, tex = inputs[0], inputs[1]
+    _, rec, saved = output
+    ctx.scalars = tuple(inputs[2:])
+    ctx.shape = (fv.shape[0], fv.shape[1])
+    ctx.has_tex = tex is not None and inputs[4] != L.SV3D_TEX_NONE
+    ctx.tex_dtype = tex.dtype if tex is not None else None
+    ctx.fv_dtype = fv.dtype
+    if ctx.has_tex:
+        ctx.save_for_backward(tex, rec, saved)
+    else:
+        ctx.save_for_backward(rec, saved)
+
+
+def _raster_backward(ctx, grad_rgba, grad_rec, grad_saved):
+    if ctx.has_tex:
+        tex, rec, saved = ctx.saved_tensors
+    else:
+        tex = None
+        rec, saved = ctx.saved_tensors
+    need_tex = ctx.has_tex and ctx.needs_input_grad[1]
+    gfv, gtex = soft_rasterize_backward_op(grad_rgba, tex, rec, saved, ctx.shape[0], ctx.shape[1],
+                                           *ctx.scalars, need_tex)
+    gfv = gfv.to(ctx.fv_dtype)
+    gtex = gtex.to(ctx.tex_dtype) if need_tex else None
+    return (gfv, gtex) + (None,) * len(ctx.scalars)
+
+
+soft_rasterize_op.register_autograd(_raster_backward, setup_context=_raster_setup_context)
+
+
+def soft_rasterize(face_vertices, textures=None, image_size=256, *, anti_aliasing=False,
+                   texture_type="surface", background_color=(0.0, 0.0, 0.0), near=1.0, far=100.0,
+                   eps=1e-3, sigma_val=1e-5, dist_eps=1e-10, gamma_val=1e-4, fill_back=True):
+    """Soft rasterization of `face_vertices` [B,F,3,3] -> RGBA [B,4,image_size,image_size].
+
+    `textures`: None renders the silhouette only (RGB = background); [B,F,R*R,3] for
+    texture_type 'surface'; [B,F,3,3] per-corner colours for 'vertex'.  With
+    `anti_aliasing` fragments are evaluated at twice the resolution and average-pooled
+    inside the kernel.
+    """
+    aa = 2 if anti_aliasing else 1
+    if textures is None:
+        mode, res = L.SV3D_TEX_NONE, 1
+    elif texture_type == "surface":
+        mode = L.SV3D_TEX_SURFACE
+        res = int(round(textures.shape[2] ** 0.5))
+        if res * res != textures.shape[2]:
+            raise ValueError("surface textures need a square texel count, got %d" % textures.shape[2])
+    elif texture_type == "vertex":
+        mode, res = L.SV3D_TEX_VERTEX, 1
+    else:
+        raise ValueError("unknown texture_type %r" % (texture_type,))
+    rgba, _, _ = soft_rasterize_op(face_vertices, textures, int(image_size) * aa, aa, mode, res,
+                                   bool(fill_back), [float(c) for c in background_color],
+                                   float(near), float(far), float(eps), float(sigma_val),
+                                   float(dist_eps), float(gamma_val))
+    return rgba
+
+
+# ---- chamfer --------------------------------------------------------------------------
+def _check_clouds(xyz1, xyz2):
+    if xyz1.dim() != 3 or xyz2.dim() != 3 or xyz1.shape[2] != 3 or xyz2.shape[2] != 3 \
+            or xyz1.shape[0] != xyz2.shape[0]:
+        raise ValueError("point clouds must be [B,N,3] and [B,M,3], got %s and %s"
+                         % (tuple(xyz1.shape), tuple(xyz2.shape)))
+    if xyz1.shape[1] == 0 or xyz2.shape[1] == 0 or xyz1.shape[0] == 0:
+        raise ValueError("empty point cloud")
+
+
+@torch.library.custom_op("sv3d::chamfer_nn", mutates_args=(), device_types="cuda")
+def chamfer_nn_op(xyz1: Tensor, xyz2: Tensor) -> Tuple[Tensor, Tensor, Tensor, Tensor]:
+    _check_clouds(xyz1, xyz2)
+    a, b = _f32c(xyz1), _f32c(xyz2)
+    B, N, M = a.shape[0], a.shape[1], b.shape[1]
+    with torch.cuda.device(a.device):
+        d1 = torch.empty((B, N), dtype=torch.float32, device=a.device)
+        d2 = torch.empty((B, M), dtype=torch.float32, device=a.device)
+        i1 = torch.empty((B, N), dtype=torch.int32, device=a.device)
+        i2 = torch.empty((B, M), dtype=torch.int32, device=a.device)
+        L.check(L.lib().sv3d_chamfer_forward(_ptr(a), _ptr(b), B, N, M, _ptr(d1), _ptr(d2),
+                                             _ptr(i1), _ptr(i2), _stream(a)), "sv3d_chamfer_forward")
+    return d1, d2, i1, i2
+
+
+@chamfer_nn_op.register_fake
+def _(xyz1, xyz2):
+    B, N, M = xyz1.shape[0], xyz1.shape[1], xyz2.shape[1]
+    return (xyz1.new_empty((B, N), dtype=torch.float32), xyz1.new_empty((B, M), dtype=torch.float32),
+            xyz1.new_empty((B, N), dtype=torch.int32), xyz1.new_empty((B, M), dtype=torch.int32))
+
+
+@torch.library.custom_op("sv3d::chamfer_nn_backward", mutates_args=(), device_types="cuda")
+def chamfer_nn_backward_op(xyz1: Tensor, xyz2: Tensor, grad_dist1: Optional[Tensor],
+                           grad_dist2: Optional[Tensor], idx1: Tensor, idx2: Tensor,
+                           need1: bool, need2: bool) -> Tuple[Tensor, Tensor]:
+    a, b = _f32c(xyz1), _f32c(xyz2)
+    B, N, M = a.shape[0], a.shape[1], b.shape[1]
+    gd1 = _f32c(grad_dist1) if grad_dist1 is not None else None
+    gd2 = _f32c(grad_dist2) if grad_dist2 is not None else None
+    with torch.cuda.device(a.device):
+        g1 = torch.empty_like(a) if need1 else torch.empty(0, dtype=torch.float32, device=a.device)
+        g2 = torch.empty_like(b) if need2 else torch.empty(0, dtype=torch.float32, device=a.device)
+        L.check(L.lib().sv3d_chamfer_backward(_ptr(a), _ptr(b), B, N, M, _ptr(gd1), _ptr(gd2),
+                                              _ptr(idx1), _ptr(idx2), _ptr(g1), _ptr(g2), _stream(a)),
+                "sv3d_chamfer_backward")
+    return g1, g2
+
+
+@chamfer_nn_backward_op.register_fake
+def _(xyz1, xyz2, grad_dist1, grad_dist2, idx1, idx2, need1, need2):
+    e = xyz1.new_empty((0,), dtype=torch.float32)
+    return (torch.empty_like(xyz1, dtype=torch.float32) if need1 else e,
+            torch.empty_like(xyz2, dtype=torch.float32) if need2 else e)
+
+
+def _chamfer_setup_context(ctx, inputs, output):
+    xyz1, xyz2 = inputs
+    _, _, i1, i2 = output
+    ctx.save_for_backward(xyz1, xyz2, i1, i2)
+
+
+def _chamfer_backward(ctx, gd1, gd2, gi1, gi2):
+    xyz1, xyz2, i1, i2 = ctx.saved_tensors
+    need1, need2 = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+    if not (need1 or need2):
+        return None, None
+    g1, g2 = chamfer_nn_backward_op(xyz1, xyz2, gd1, gd2, i1, i2, need1, need2)
+    return (g1.to(xyz1.dtype) if need1 else None, g2.to(xyz2.dtype) if need2 else None)
+
+
+chamfer_nn_op.register_autograd(_chamfer_backward, setup_context=_chamfer_setup_context)
+
+
+def chamfer_nn(xyz1, xyz2):
+    """(dist1 [B,N], dist2 [B,M], idx1 [B,N] int32, idx2 [B,M] int32); squared distances."""
+    return chamfer_nn_op(xyz1, xyz2)
+
+
+# ---- mesh gather / scatter ------------------------------------------------------------
+@torch.library.custom_op("sv3d::face_gather", mutates_args=(), device_types="cuda")
+def face_gather_op(values: Tensor, faces: Tensor, scale: List[float], shift: List[float]) -> Tensor:
+    if values.dim() != 3 or values.shape[2] != 3:
+        raise ValueError("values must be [B,V,3], got %s" % (tuple(values.shape),))
+    if faces.dim() != 3 or faces.shape[2] != 3 or faces.dtype != torch.int32 \
+            or faces.shape[0] not in (1, values.shape[0]):
+        raise ValueError("faces must be int32 [B or 1,F,3], got %s %s" % (faces.dtype, tuple(faces.shape)))
+    v = _f32c(values)
+    f = faces.contiguous()
+    B, V, F = v.shape[0], v.shape[1], f.shape[1]
+    with torch.cuda.device(v.device):
+        out = torch.empty((B, F, 3, 3), dtype=torch.float32, device=v.device)
+        L.check(L.lib().sv3d_face_gather(_ptr(v), _ptr(f), B, V, F, f.shape[0], L.float3(scale),
+                                         L.float3(shift), _ptr(out), _stream(v)), "sv3d_face_gather")
+    return out
+
+
+@face_gather_op.register_fake
+def _(values, faces, scale, shift):
+    return values.new_empty((values.shape[0], faces.shape[1], 3, 3), dtype=torch.float32)
+
+
+@torch.library.custom_op("sv3d::face_scatter", mutates_args=(), device_types="cuda")
+def face_scatter_op(grad_out: Tensor, faces: Tensor, num_vertices: int, scale: List[float]) -> Tensor:
+    g = _f32c(grad_out)
+    B, F = g.shape[0], g.shape[1]
+    with torch.cuda.device(g.device):
+        out = torch.empty((B, num_vertices, 3), dtype=torch.float32, device=g.device)
+        L.check(L.lib().sv3d_face_scatter(_ptr(g), _ptr(faces), B, num_vertices, F, faces.shape[0],
+                                          L.float3(scale), _ptr(out), _stream(g)), "sv3d_face_scatter")
+    return out
+
+
+@face_scatter_op.register_fake
+def _(grad_out, faces, num_vertices, scale):
+    return grad_out.new_empty((grad_out.shape[0], num_vertices, 3), dtype=torch.float32)
+
+
+def _gather_setup_context(ctx, inputs, output):
+    values, faces, scale, _ = inputs
+    ctx.save_for_backward(faces)
+    ctx.num_vertices = values.shape[1]
+    ctx.scale = list(scale)
+    ctx.dtype = values.dtype
+
+
+def _gather_backward(ctx, grad_out):
+    (faces,) = ctx.saved_tensors
+    g = face_scatter_op(grad_out, faces, ctx.num_vertices, ctx.scale)
+    return g.to(ctx.dtype), None, None, None
+
+
+face_gather_op.register_autograd(_gather_backward, setup_context=_gather_setup_context)
+
+
+def face_gather(values, faces, scale=(1.0, 1.0, 1.0), shift=(0.0, 0.0, 0.0)):
+    """out[b,f,k,:] = values[b, faces[b or 0, f, k], :] * scale + shift -> [B,F,3,3]."""
+    if faces.dtype != torch.int32:
+        faces = faces.to(torch.int32)
+    return face_gather_op(values, faces.contiguous(), [float(s) for s in scale],
+                          [float(s) for s in shift])
