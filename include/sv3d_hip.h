@@ -88,6 +88,21 @@ int sv3d_raster_backward(const sv3d_raster_params *p, const float *textures,
                          float *grad_textures, void *workspace, size_t workspace_bytes,
                          void *stream);
 
+/* Measurement variants of the two calls above.  They have no counterpart in the reference
+ * (which has no timing harness); they exist for benchmarks that must time one kernel on
+ * the stream it runs on.  Same work and results as the plain calls; in addition the two
+ * hipEvent_t (passed as void*, either may be NULL) are recorded on `stream` immediately
+ * before and after the call's dominant kernel: the per-tile fragment kernel for forward,
+ * the per-face gradient kernel for backward. */
+int sv3d_raster_forward_timed(const sv3d_raster_params *p, const float *face_vertices,
+                              const float *textures, float *rgba_out, void *face_rec,
+                              void *pixel_saved, void *stream, void *ev_start, void *ev_stop);
+int sv3d_raster_backward_timed(const sv3d_raster_params *p, const float *textures,
+                               const void *face_rec, const void *pixel_saved,
+                               const float *grad_rgba, float *grad_face_vertices,
+                               float *grad_textures, void *workspace, size_t workspace_bytes,
+                               void *stream, void *ev_start, void *ev_stop);
+
 /* Replaces chamferdist's forward as called at nnutils/loss_utils.py:85-86
  * (`ChamferDistance()(xyz1, xyz2)`).
  *   xyz1 [B,N,3], xyz2 [B,M,3] -> dist1 [B,N], dist2 [B,M] (SQUARED distances),

@@ -159,7 +159,10 @@ __device__ inline PairDepth pair_depth(const FaceRec &r, const PairGeom &g, cons
     const float wc0 = sat(g.w0), wc1 = sat(g.w1), wc2 = sat(g.w2);
     const float num = wc0 * r.q0 + wc1 * r.q1 + wc2 * r.q2;
     const float den = wc0 * r.iz0 + wc1 * r.iz1 + wc2 * r.iz2;
-    d.u = num * rcp(den);
+    // one Newton step on the reciprocal: the z-softmax divides this offset by (far-near)*gamma
+    float rden = rcp(den);
+    rden = rden * (2.f - den * rden);
+    d.u = num * rden;
     d.zp = r.zref + d.u;
     d.rs = rcp(wc0 + wc1 + wc2);
     d.n0 = wc0 * d.rs;
@@ -171,11 +174,12 @@ __device__ inline PairDepth pair_depth(const FaceRec &r, const PairGeom &g, cons
     return d;
 }
 
-__device__ inline int texel_index(float n0, float n1, int R)
+__device__ inline int texel_index(float n0, float n1, float n2, int R)
 {
     const float fx = n0 * (float)R, fy = n1 * (float)R;
     const int wx = min((int)fx, R - 1), wy = min((int)fy, R - 1);
-    const bool lower = ((n0 + n1) * (float)R - (float)wx) - (float)wy <= 1.f;
+    // (n0 + n1) written as (1 - n2): identical in exact arithmetic, and exact on a clamped edge
+    const bool lower = ((1.f - n2) * (float)R - (float)wx) - (float)wy <= 1.f;
     return lower ? wy * R + wx : (R - 1 - wy) * R + (R - 1 - wx);
 }
 
@@ -306,7 +310,7 @@ __global__ __launch_bounds__(kThreads) void raster_forward_kernel(
                         if (MODE == SV3D_TEX_SURFACE) {
                             const int Ts = P.R * P.R;
                             const float *tp = tex + (((size_t)b * F + fid) * Ts +
-                                                     texel_index(d.n0, d.n1, P.R)) * 3;
+                                                     texel_index(d.n0, d.n1, d.n2, P.R)) * 3;
                             k0 = tp[0]; k1 = tp[1]; k2 = tp[2];
                         } else {
                             const float *tp = tex + ((size_t)b * F + fid) * 9;
@@ -366,6 +370,7 @@ __global__ __launch_bounds__(kThreads) void raster_forward_kernel(
     } else {
         o0 = P.bg0; o1 = P.bg1; o2 = P.bg2;
     }
+    A = fminf(A, 1.f);                          // e*rcp(1+e) may round a hair above 1
     float o3 = 1.f - A;
     const bool inimg = col < S && row < S;
     if (inimg) {
@@ -530,7 +535,7 @@ __global__ __launch_bounds__(kThreads) void raster_backward_kernel(
                 float k0, k1, k2;
                 int tid = 0;
                 if (MODE == SV3D_TEX_SURFACE) {
-                    tid = texel_index(d.n0, d.n1, P.R);
+                    tid = texel_index(d.n0, d.n1, d.n2, P.R);
                     const float *tp = tex + ((size_t)gf * Ts + tid) * 3;
                     k0 = tp[0]; k1 = tp[1]; k2 = tp[2];
                 } else {
@@ -668,9 +673,11 @@ extern "C" int sv3d_raster_sizes(const sv3d_raster_params *p, size_t *face_rec_b
     return SV3D_OK;
 }
 
-extern "C" int sv3d_raster_forward(const sv3d_raster_params *p, const float *face_vertices,
-                                   const float *textures, float *rgba_out, void *face_rec,
-                                   void *pixel_saved, void *stream)
+namespace {
+
+int raster_forward_impl(const sv3d_raster_params *p, const float *face_vertices, const float *textures,
+                        float *rgba_out, void *face_rec, void *pixel_saved, void *stream,
+                        hipEvent_t ev_start, hipEvent_t ev_stop)
 {
     DevParams d;
     const int st = make_dev_params(p, d);
@@ -686,20 +693,21 @@ extern "C" int sv3d_raster_forward(const sv3d_raster_params *p, const float *fac
     const int tiles = (d.S + kTile - 1) / kTile;
     dim3 grid(tiles, tiles, d.B), block(kThreads);
     float *saved = static_cast<float *>(pixel_saved);
+    if (ev_start) (void)hipEventRecord(ev_start, s);
     if (d.mode == SV3D_TEX_NONE)
         hipLaunchKernelGGL(raster_forward_kernel<SV3D_TEX_NONE>, grid, block, 0, s, d, rec, pbox, textures, rgba_out, saved);
     else if (d.mode == SV3D_TEX_SURFACE)
         hipLaunchKernelGGL(raster_forward_kernel<SV3D_TEX_SURFACE>, grid, block, 0, s, d, rec, pbox, textures, rgba_out, saved);
     else
         hipLaunchKernelGGL(raster_forward_kernel<SV3D_TEX_VERTEX>, grid, block, 0, s, d, rec, pbox, textures, rgba_out, saved);
+    if (ev_stop) (void)hipEventRecord(ev_stop, s);
     return launch_status();
 }
 
-extern "C" int sv3d_raster_backward(const sv3d_raster_params *p, const float *textures,
-                                    const void *face_rec, const void *pixel_saved,
-                                    const float *grad_rgba, float *grad_face_vertices,
-                                    float *grad_textures, void *workspace, size_t workspace_bytes,
-                                    void *stream)
+int raster_backward_impl(const sv3d_raster_params *p, const float *textures, const void *face_rec,
+                         const void *pixel_saved, const float *grad_rgba, float *grad_face_vertices,
+                         float *grad_textures, void *workspace, size_t workspace_bytes, void *stream,
+                         hipEvent_t ev_start, hipEvent_t ev_stop)
 {
     DevParams d;
     const int st = make_dev_params(p, d);
@@ -719,17 +727,61 @@ extern "C" int sv3d_raster_backward(const sv3d_raster_params *p, const float *te
     const dim3 fgrid((d.B * d.F + 3) / 4);
     if (d.mode == SV3D_TEX_NONE) {
         hipLaunchKernelGGL(raster_prep_kernel<SV3D_TEX_NONE>, pgrid, block, 0, s, d, saved, grad_rgba, prep);
+        if (ev_start) (void)hipEventRecord(ev_start, s);
         hipLaunchKernelGGL(raster_backward_kernel<SV3D_TEX_NONE>, fgrid, block, 0, s, d, rec, pbox,
                            textures, prep, grad_face_vertices, (float *)nullptr);
     } else if (d.mode == SV3D_TEX_SURFACE) {
         const size_t lds = (size_t)4 * d.R * d.R * 3 * sizeof(float);
         hipLaunchKernelGGL(raster_prep_kernel<SV3D_TEX_SURFACE>, pgrid, block, 0, s, d, saved, grad_rgba, prep);
+        if (ev_start) (void)hipEventRecord(ev_start, s);
         hipLaunchKernelGGL(raster_backward_kernel<SV3D_TEX_SURFACE>, fgrid, block, lds, s, d, rec, pbox,
                            textures, prep, grad_face_vertices, grad_textures);
     } else {
         hipLaunchKernelGGL(raster_prep_kernel<SV3D_TEX_VERTEX>, pgrid, block, 0, s, d, saved, grad_rgba, prep);
+        if (ev_start) (void)hipEventRecord(ev_start, s);
         hipLaunchKernelGGL(raster_backward_kernel<SV3D_TEX_VERTEX>, fgrid, block, 0, s, d, rec, pbox,
                            textures, prep, grad_face_vertices, grad_textures);
     }
+    if (ev_stop) (void)hipEventRecord(ev_stop, s);
     return launch_status();
+}
+
+}  // namespace
+
+extern "C" int sv3d_raster_forward(const sv3d_raster_params *p, const float *face_vertices,
+                                   const float *textures, float *rgba_out, void *face_rec,
+                                   void *pixel_saved, void *stream)
+{
+    return raster_forward_impl(p, face_vertices, textures, rgba_out, face_rec, pixel_saved, stream,
+                               nullptr, nullptr);
+}
+
+extern "C" int sv3d_raster_forward_timed(const sv3d_raster_params *p, const float *face_vertices,
+                                         const float *textures, float *rgba_out, void *face_rec,
+                                         void *pixel_saved, void *stream, void *ev_start, void *ev_stop)
+{
+    return raster_forward_impl(p, face_vertices, textures, rgba_out, face_rec, pixel_saved, stream,
+                               static_cast<hipEvent_t>(ev_start), static_cast<hipEvent_t>(ev_stop));
+}
+
+extern "C" int sv3d_raster_backward(const sv3d_raster_params *p, const float *textures,
+                                    const void *face_rec, const void *pixel_saved,
+                                    const float *grad_rgba, float *grad_face_vertices,
+                                    float *grad_textures, void *workspace, size_t workspace_bytes,
+                                    void *stream)
+{
+    return raster_backward_impl(p, textures, face_rec, pixel_saved, grad_rgba, grad_face_vertices,
+                                grad_textures, workspace, workspace_bytes, stream, nullptr, nullptr);
+}
+
+extern "C" int sv3d_raster_backward_timed(const sv3d_raster_params *p, const float *textures,
+                                          const void *face_rec, const void *pixel_saved,
+                                          const float *grad_rgba, float *grad_face_vertices,
+                                          float *grad_textures, void *workspace,
+                                          size_t workspace_bytes, void *stream, void *ev_start,
+                                          void *ev_stop)
+{
+    return raster_backward_impl(p, textures, face_rec, pixel_saved, grad_rgba, grad_face_vertices,
+                                grad_textures, workspace, workspace_bytes, stream,
+                                static_cast<hipEvent_t>(ev_start), static_cast<hipEvent_t>(ev_stop));
 }

@@ -1,0 +1,66 @@
+"""Drop-in for the reference's nnutils/softras.py: `SoftNeuralRenderer`.
+
+Same constructor, attributes and methods (softras.py:25-77): weak-perspective projection
+with offset_z 5, y flip, then one of three renders -- silhouette (textures None), lit RGB
+from surface textures, or unlit per-vertex colours for the part-segmentation maps.  The
+renderer underneath is the `soft_renderer` drop-in over the sv3d HIP kernels.
+"""
+import torch
+
+import soft_renderer as sr
+
+from . import geom_utils
+
+
+def convert_as(src, trg):
+    return src.to(trg.device).type_as(trg)
+
+
+class SoftNeuralRenderer(torch.nn.Module):
+    """forward(vertices [B,V,3], faces [B,F,3], cams [B,7], textures=None) ->
+    masks [B,H,W] when textures is None, else RGB [B,3,H,W]."""
+
+    def __init__(self, img_size=256, texture_type='surface'):
+        super(SoftNeuralRenderer, self).__init__()
+        # constants of softras.py:33-37
+        self.renderer = sr.SoftRenderer(image_size=img_size, camera_mode='look_at',
+                                        aggr_func_rgb='softmax', anti_aliasing=True,
+                                        sigma_val=1e-5, gamma_val=1e-4, dist_eps=1e-10,
+                                        perspective=False, light_intensity_ambient=0.8,
+                                        eye=[0, 0, -2.732], texture_type=texture_type,
+                                        light_mode=texture_type)
+        self.proj_fn = geom_utils.orthographic_proj_withz
+        self.offset_z = 5.
+        self.part_seg = texture_type == 'vertex'
+
+    def ambient_light_only(self):
+        """softras.py:43-45: ambient 1, no directional light (textures pass unchanged)."""
+        self.renderer.lighting = sr.Lighting(intensity_ambient=1., intensity_directionals=0.)
+
+    def set_bgcolor(self, color):
+        self.renderer.rasterizer.background_color = color
+
+    def set_light_dir(self, direction):
+        self.renderer.lighting.directionals[0].light_direction = direction
+
+    def project_points(self, verts, cams):
+        """softras.py:53-55: xy of the projection, no flip, no depth offset."""
+        return self.proj_fn(verts, cams)[:, :, :2]
+
+    def forward(self, vertices, faces, cams, textures=None, part_seg=False):
+        verts = self.proj_fn(vertices, cams, offset_z=self.offset_z)
+        vs = verts * verts.new_tensor([1.0, -1.0, 1.0])               # image y points down
+        if textures is None:
+            self.mask_only = True
+            # coverage only: the reference renders RGBA and keeps [:, -1] (softras.py:64)
+            mesh = sr.Mesh(vs, faces)
+            mesh = self.renderer.transform(mesh)
+            return self.renderer.rasterizer(mesh, 'silhouettes')[:, -1]
+        self.mask_only = False
+        if self.part_seg:
+            # vertex colours, no lighting (softras.py:69-75)
+            mesh = sr.Mesh(vs, faces, textures=textures, texture_type='vertex')
+            self.renderer.set_texture_mode(mesh.texture_type)
+            mesh = self.renderer.transform(mesh)
+            return self.renderer.rasterizer(mesh, None)[:, :3]
+        return self.renderer(vs, faces, textures)[:, :3]

@@ -14,7 +14,8 @@ SV3D_TEX_NONE, SV3D_TEX_SURFACE, SV3D_TEX_VERTEX = 0, 1, 2
 
 EXPORTS = (
     "sv3d_strerror", "sv3d_abi_version", "sv3d_raster_sizes", "sv3d_raster_forward",
-    "sv3d_raster_backward", "sv3d_chamfer_forward", "sv3d_chamfer_backward",
+    "sv3d_raster_backward", "sv3d_raster_forward_timed", "sv3d_raster_backward_timed",
+    "sv3d_chamfer_forward", "sv3d_chamfer_backward",
     "sv3d_face_gather", "sv3d_face_scatter",
 )
 
@@ -58,6 +59,8 @@ def lib():
         L.sv3d_raster_sizes.argtypes = [pp, ctypes.POINTER(sz), ctypes.POINTER(sz), ctypes.POINTER(sz)]
         L.sv3d_raster_forward.argtypes = [pp, vp, vp, vp, vp, vp, vp]
         L.sv3d_raster_backward.argtypes = [pp, vp, vp, vp, vp, vp, vp, vp, sz, vp]
+        L.sv3d_raster_forward_timed.argtypes = [pp, vp, vp, vp, vp, vp, vp, vp, vp]
+        L.sv3d_raster_backward_timed.argtypes = [pp, vp, vp, vp, vp, vp, vp, vp, sz, vp, vp, vp]
         L.sv3d_chamfer_forward.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp, vp, vp]
         L.sv3d_chamfer_backward.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp]
         f3 = ctypes.POINTER(ctypes.c_float)

