@@ -33,7 +33,11 @@ constexpr int kThreads = 256;
 constexpr int kRec = 32;          // floats per face record (128 B, eight float4)
 constexpr int kRec4 = kRec / 4;
 constexpr int kTile = 16;         // tile side in raster pixels
-constexpr int kListCap = 256;     // faces staged in LDS at a time (32 KiB)
+#ifndef SV3D_LIST_CAP
+#define SV3D_LIST_CAP 128
+#endif
+constexpr int kListCap = SV3D_LIST_CAP;   // faces staged in LDS at a time (128 B each)
+constexpr int kMaskCap = 256;             // 64-face hit masks per binning pass (16384 faces)
 
 struct DevParams {
     int B, F, S, aa, mode, R, double_side;
@@ -255,13 +259,21 @@ __global__ __launch_bounds__(kThreads) void raster_forward_kernel(
 {
     __shared__ float4 s_rec[kListCap * kRec4];
     __shared__ int s_ids[kListCap];
-    __shared__ int s_wtot[4];
+    __shared__ unsigned long long s_mask[kMaskCap];
+    __shared__ int s_moff[kMaskCap];
+    __shared__ int s_total;
 
-    const int b = blockIdx.z;
+    // Workgroup id -> (image, tile) with the image index fastest: workgroups that land on one
+    // CU (ids a multiple of the CU count apart) then come from tile positions spread over the
+    // screen, instead of the same position of every image, which balances silhouette-ring tiles
+    // (many faces) against empty corners.
+    const int tiles_x = (P.S + kTile - 1) / kTile;
+    const int b = blockIdx.x % P.B;
+    const int tile = blockIdx.x / P.B;
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int S = P.S, F = P.F;
-    const int tile_c0 = blockIdx.x * kTile, tile_r0 = blockIdx.y * kTile;
+    const int tile_c0 = (tile % tiles_x) * kTile, tile_r0 = (tile / tiles_x) * kTile;
     // lane -> pixel of the wave's 8x8 block; lanes 4q..4q+3 form the 2x2 quad q
     const int quad = lane >> 2, sub = lane & 3;
     const int blk_c0 = tile_c0 + (wave & 1) * 8, blk_r0 = tile_r0 + (wave >> 1) * 8;
@@ -334,33 +346,72 @@ __global__ __launch_bounds__(kThreads) void raster_forward_kernel(
         __syncthreads();
     };
 
-    // Ordered compaction of the faces whose pixel box touches this tile.
+    // ---- binning: the faces whose pixel box touches this tile, in face order ----------------
+    // One pass over the compact box array; a wave's loads are independent, so their latencies
+    // overlap.  The hit bits of 64 consecutive faces are kept as one 64-bit mask in LDS, an
+    // exclusive scan of the mask popcounts gives every hit its list position, and the list is
+    // consumed in windows of kListCap faces.
     const int tc1 = tile_c0 + kTile - 1, tr1 = tile_r0 + kTile - 1;
-    int count = 0;
-    for (int base = 0; base < F; base += kThreads) {
-        const int f = base + (int)threadIdx.x;
-        bool hit = false;
-        if (f < F) {
-            int c0, c1, r0, r1;
-            unpack_box(pbox_b[f], c0, c1, r0, r1);
-            hit = !(c1 < tile_c0 || c0 > tc1 || r1 < tile_r0 || r0 > tr1);
+    const unsigned long long lane_lt = (1ull << lane) - 1ull;
+    for (int fbase = 0; fbase < F; fbase += kMaskCap * 64) {
+        const int nmask = (min(F - fbase, kMaskCap * 64) + 63) >> 6;
+        for (int m0 = wave; m0 < nmask; m0 += 16) {      // four masks per wave per trip
+            uint2 bx[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {                // four independent loads in flight
+                const int f = fbase + (m0 + 4 * k) * 64 + lane;
+                bx[k] = f < F ? pbox_b[f] : make_uint2(0xffff7fffu, 0xffff7fffu);   // empty box
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int mi = m0 + 4 * k;
+                if (mi < nmask) {                        // wave-uniform
+                    int c0, c1, r0, r1;
+                    unpack_box(bx[k], c0, c1, r0, r1);
+                    const bool hit = !(c1 < tile_c0 || c0 > tc1 || r1 < tile_r0 || r0 > tr1);
+                    const unsigned long long mask = __ballot(hit);
+                    if (lane == 0) s_mask[mi] = mask;
+                }
+            }
         }
-        const unsigned long long mask = __ballot(hit);
-        const int prefix = __popcll(mask & ((1ull << lane) - 1ull));
-        if (lane == 0) s_wtot[wave] = __popcll(mask);
         __syncthreads();
-        const int t0 = s_wtot[0], t1 = s_wtot[1], t2 = s_wtot[2], t3 = s_wtot[3];
-        const int total = t0 + t1 + t2 + t3;
-        if (count + total > kListCap) {        // block-uniform
-            process_list(count);
-            count = 0;
+        if (wave == 0) {                        // lane l scans masks 4l .. 4l+3
+            int c[4], sum = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int mi = 4 * lane + k;
+                c[k] = mi < nmask ? __popcll(s_mask[mi]) : 0;
+                sum += c[k];
+            }
+            int incl = sum;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const int t = __shfl_up(incl, d);
+                if (lane >= d) incl += t;
+            }
+            int run = incl - sum;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                s_moff[4 * lane + k] = run;
+                run += c[k];
+            }
+            if (lane == 63) s_total = incl;
         }
-        const int woff = (wave > 0 ? t0 : 0) + (wave > 1 ? t1 : 0) + (wave > 2 ? t2 : 0);
-        if (hit) s_ids[count + woff + prefix] = f;
-        count += total;
+        __syncthreads();
+        const int total = s_total;
+        for (int win = 0; win < total; win += kListCap) {
+            for (int mi = wave; mi < nmask; mi += 4) {
+                const unsigned long long mask = s_mask[mi];
+                if ((mask >> lane) & 1ull) {
+                    const int pos = s_moff[mi] + __popcll(mask & lane_lt) - win;
+                    if (pos >= 0 && pos < kListCap) s_ids[pos] = fbase + mi * 64 + lane;
+                }
+            }
+            __syncthreads();
+            process_list(min(kListCap, total - win));
+        }
         __syncthreads();
     }
-    if (count > 0) process_list(count);
 
     // epilogue
     float o0, o1, o2;
@@ -501,27 +552,34 @@ __global__ __launch_bounds__(kThreads) void raster_backward_kernel(
 #pragma unroll
     for (int i = 0; i < 9; ++i) { acc[i] = 0.f; tacc[i] = 0.f; }
 
+    // Lanes enumerate the box row-major, 64 pixels per step.  Index arithmetic in fp32 is
+    // exact here (a box holds < 2^24 pixels because S <= 4096).
+    const float bw_f = (float)bw;
+    const float step = 2.f / (float)S;
+    float xp0, yp0;
+    pixel_centre(col0, row0, S, xp0, yp0);
+    const float *prep_b = prep + (size_t)b * S * S * (MODE == SV3D_TEX_NONE ? 1 : 6);
     for (int base = 0; base < npix; base += 64) {
         const int idx = base + lane;
         const bool valid = idx < npix;
-        int ry = (int)(((float)idx + 0.5f) * inv_bw);
-        int rx = idx - ry * bw;
-        if (rx < 0) { ry -= 1; rx += bw; }
-        if (rx >= bw) { ry += 1; rx -= bw; }
-        const int col = valid ? col0 + rx : col0;
-        const int row = valid ? row0 + ry : row0;
-        float xp, yp;
-        pixel_centre(col, row, S, xp, yp);
-        const size_t pix = ((size_t)b * S + row) * S + col;
+        const float idx_f = (float)idx;
+        float ry_f = floorf((idx_f + 0.5f) * inv_bw);
+        float rx_f = fmaf(-ry_f, bw_f, idx_f);
+        if (rx_f < 0.f) { ry_f -= 1.f; rx_f += bw_f; }
+        if (rx_f >= bw_f) { ry_f += 1.f; rx_f -= bw_f; }
+        if (!valid) { rx_f = 0.f; ry_f = 0.f; }
+        const float xp = fmaf(rx_f, step, xp0);
+        const float yp = fmaf(-ry_f, step, yp0);
+        const unsigned pix = (unsigned)(row0 + (int)ry_f) * (unsigned)S + (unsigned)(col0 + (int)rx_f);
 
         PairGeom g = pair_geom(r, xp, yp, P);
         const bool act = valid && g.act;
         float P0;
         float G0 = 0.f, G1 = 0.f, G2 = 0.f, Rr = 0.f, mfin = 0.f;
         if (MODE == SV3D_TEX_NONE) {
-            P0 = prep[pix];
+            P0 = prep_b[pix];
         } else {
-            const float2 *pp = (const float2 *)(prep + pix * 6);
+            const float2 *pp = (const float2 *)(prep_b + pix * 6u);
             const float2 a0 = pp[0], a1 = pp[1], a2 = pp[2];
             P0 = a0.x; G0 = a0.y; G1 = a1.x; G2 = a1.y; Rr = a2.x; mfin = a2.y;
         }
@@ -629,7 +687,7 @@ int make_dev_params(const sv3d_raster_params *p, DevParams &d)
     if (!(p->sigma > 0.f) || !(p->gamma > 0.f) || !(p->dist_eps > 0.f) || !(p->dist_eps < 1.f))
         return SV3D_ERR_INVALID_ARG;
     if (!(p->far_plane > p->near_plane)) return SV3D_ERR_INVALID_ARG;
-    if (p->raster_size > 16384 || p->batch > 65535) return SV3D_ERR_UNSUPPORTED;
+    if (p->raster_size > 4096 || p->batch > 65535) return SV3D_ERR_UNSUPPORTED;
     if ((long)p->batch * p->num_faces > 0x7fffffffL / 4) return SV3D_ERR_UNSUPPORTED;
     if (p->texture_mode == SV3D_TEX_SURFACE && p->texture_res > 36) return SV3D_ERR_UNSUPPORTED;
     const double l2e = 1.4426950408889634;
@@ -691,7 +749,7 @@ int raster_forward_impl(const sv3d_raster_params *p, const float *face_vertices,
     hipLaunchKernelGGL(raster_setup_kernel, dim3((nf + kThreads - 1) / kThreads), dim3(kThreads), 0, s,
                        d, face_vertices, rec, pbox);
     const int tiles = (d.S + kTile - 1) / kTile;
-    dim3 grid(tiles, tiles, d.B), block(kThreads);
+    dim3 grid((unsigned)tiles * tiles * d.B), block(kThreads);
     float *saved = static_cast<float *>(pixel_saved);
     if (ev_start) (void)hipEventRecord(ev_start, s);
     if (d.mode == SV3D_TEX_NONE)
