@@ -1,0 +1,276 @@
+"""Generic trainer with the hooks and loop of the reference's nnutils/train_utils.py
+(`Trainer`, train_utils.py:62-256), extended to one process per GPU.
+
+What is kept: the subclass hooks (`define_model`, `init_dataset`, `define_criterion`,
+`set_input`, `forward` -> `self.total_loss`, `get_current_scalars`), Adam for `self.model` and
+a second Adam for `self.part_basis_generator` when `opts.seg_train and not opts.query_basis`
+(:161-172), autocast + GradScaler, unscale -> clip_grad_norm_(0.1) -> step per optimizer
+(:201-214), the 0.99/0.01 smoothed loss (:194), `{label}_net_{epoch}.pth` snapshots of the
+bare module's state_dict (:84-99) every `save_latest_freq` iterations / `save_epoch_freq`
+epochs (:232-253), `num_iter` early stop (:240) and the cut of every epoch after 10 % of the
+loader (:243-244, `opts.epoch_fraction`).
+
+What is new (the reference is single-process, `--gpu_id`): the batch shards by image, so
+training scales as data parallel replicas.  `init_distributed()` reads RANK / LOCAL_RANK /
+WORLD_SIZE (torch.distributed.run), binds the rank to its GPU before any model code runs and
+opens the "nccl" (= RCCL over xGMI) process group, or "gloo" on CPU.  `init_training()` wraps
+the model(s) in DistributedDataParallel, whose bucketed gradient all-reduce overlaps with the
+rasterizer's backward; the rasterizer and Chamfer kernels themselves need no collective.
+Clipping runs on the already averaged gradients, so every rank takes the same step.  Rank 0
+alone writes snapshots and logs; scalars are averaged over ranks every `print_freq` steps.
+BatchNorm statistics stay per rank (no SyncBN), as a single-GPU run of the reference has them
+per batch.
+"""
+import argparse
+import os
+import time
+
+import torch
+import torch.distributed as dist
+
+
+def add_training_flags(parser=None):
+    """argparse twin of the reference's absl flags (train_utils.py:27-56)."""
+    p = parser or argparse.ArgumentParser()
+    p.add_argument('--name', default='exp_name')
+    p.add_argument('--gpu_id', type=int, default=0)
+    p.add_argument('--num_epochs', type=int, default=1000)
+    p.add_argument('--num_pretrain_epochs', type=int, default=0)
+    p.add_argument('--learning_rate', type=float, default=0.0001)
+    p.add_argument('--beta1', type=float, default=0.9)
+    p.add_argument('--use_sgd', action='store_true')
+    p.add_argument('--batch_size', type=int, default=4, help='per-process minibatch')
+    p.add_argument('--num_iter', type=int, default=0)
+    p.add_argument('--checkpoint_dir', default=os.path.join(os.getcwd(), 'snapshots'))
+    p.add_argument('--print_freq', type=int, default=10)
+    p.add_argument('--save_latest_freq', type=int, default=5000)
+    p.add_argument('--save_epoch_freq', type=int, default=25)
+    p.add_argument('--print_scalars', type=int, default=1)
+    p.add_argument('--seg_train', type=int, default=0)
+    p.add_argument('--query_basis', type=int, default=0)
+    p.add_argument('--grad_clip', type=float, default=0.1)
+    p.add_argument('--epoch_fraction', type=float, default=0.1)
+    p.add_argument('--amp', type=int, default=1)
+    p.add_argument('--seed', type=int, default=0)
+    return p
+
+
+class DistEnv(object):
+    """Rank bookkeeping of one process."""
+
+    def __init__(self, rank=0, local_rank=0, world_size=1, device=None, backend=None):
+        self.rank, self.local_rank, self.world_size = rank, local_rank, world_size
+        self.device = device if device is not None else torch.device('cpu')
+        self.backend = backend
+
+    @property
+    def is_main(self):
+        return self.rank == 0
+
+    @property
+    def distributed(self):
+        return self.world_size > 1
+
+
+def init_distributed(backend=None, gpu_id=0):
+    """Open the process group described by the environment (no-op for a single process).
+    Must run before the model is built: it selects this rank's GPU."""
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', str(gpu_id)))
+    use_cuda = torch.cuda.is_available() and backend != 'gloo'
+    if use_cuda:
+        if world == 1:
+            local_rank = gpu_id
+        torch.cuda.set_device(local_rank)
+        device = torch.device('cuda', local_rank)
+    else:
+        device = torch.device('cpu')
+    if world > 1 and not dist.is_initialized():
+        backend = backend or ('nccl' if use_cuda else 'gloo')
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        kwargs = {'device_id': device} if backend == 'nccl' else {}
+        dist.init_process_group(backend, rank=rank, world_size=world, **kwargs)
+    return DistEnv(rank, local_rank, world, device, backend if world > 1 else None)
+
+
+def unwrap(module):
+    return module.module if isinstance(module, torch.nn.parallel.DistributedDataParallel) else module
+
+
+class Trainer(object):
+    def __init__(self, opts, env=None):
+        self.opts = opts
+        self.env = env if env is not None else init_distributed(gpu_id=getattr(opts, 'gpu_id', 0))
+        self.device = self.env.device
+        self.gpu_id = self.env.local_rank if self.device.type == 'cuda' else None
+        self.invalid_batch = False      # a subclass may set this in set_input to skip the step
+        self.save_dir = os.path.join(opts.checkpoint_dir, opts.name)
+        torch.manual_seed(getattr(opts, 'seed', 0) + self.env.rank)
+        if self.env.is_main:
+            os.makedirs(self.save_dir, exist_ok=True)
+            with open(os.path.join(self.save_dir, 'opts.log'), 'w') as f:
+                for k, v in sorted(vars(opts).items()):
+                    f.write('{}: {}\n'.format(k, v))
+
+    # ---- snapshots (train_utils.py:84-99) ----------------------------------------------
+    def save_network(self, network, network_label, epoch_label, gpu_id=None):
+        if not self.env.is_main:
+            return
+        save_path = os.path.join(self.save_dir, '{}_net_{}.pth'.format(network_label, epoch_label))
+        state = {k: v.detach().cpu() for k, v in unwrap(network).state_dict().items()}
+        torch.save(state, save_path)
+
+    def load_network(self, network, network_label, epoch_label, network_dir=None):
+        save_path = os.path.join(network_dir or self.save_dir,
+                                 '{}_net_{}.pth'.format(network_label, epoch_label))
+        unwrap(network).load_state_dict(torch.load(save_path, map_location=self.device, weights_only=True))
+
+    # ---- hooks ---------------------------------------------------------------------------
+    def define_model(self):
+        raise NotImplementedError
+
+    def init_dataset(self):
+        raise NotImplementedError
+
+    def define_criterion(self):
+        raise NotImplementedError
+
+    def set_input(self, batch):
+        raise NotImplementedError
+
+    def forward(self, total_steps=0):
+        '''Should compute self.total_loss.'''
+        raise NotImplementedError
+
+    def get_current_scalars(self):
+        return {'total_loss': float(self.total_loss.detach()),
+                'smoothed_total_loss': float(self.smoothed_total_loss)}
+
+    def save(self, epoch_prefix):
+        self.save_network(self.model, 'pred', epoch_prefix, gpu_id=self.gpu_id)
+
+    def save_basis(self, epoch_prefix):
+        self.save_network(self.part_basis_generator, 'part_basis', epoch_prefix, gpu_id=self.gpu_id)
+
+    # ---- set-up --------------------------------------------------------------------------
+    def _second_optimizer(self):
+        o = self.opts
+        return bool(getattr(o, 'seg_train', 0)) and not bool(getattr(o, 'query_basis', 0)) \
+            and hasattr(self, 'part_basis_generator')
+
+    def _wrap(self, module):
+        module = module.to(self.device)
+        if not self.env.distributed or not any(p.requires_grad for p in module.parameters()):
+            return module
+        ids = [self.env.local_rank] if self.device.type == 'cuda' else None
+        return torch.nn.parallel.DistributedDataParallel(module, device_ids=ids, broadcast_buffers=False)
+
+    def make_sampler(self, dataset, shuffle=True):
+        """DistributedSampler replacing the reference loader's shuffle=True
+        (data/base.py:215-222); keep drop_last=True on the DataLoader."""
+        if not self.env.distributed:
+            return None
+        return torch.utils.data.distributed.DistributedSampler(
+            dataset, num_replicas=self.env.world_size, rank=self.env.rank, shuffle=shuffle,
+            drop_last=True)
+
+    def init_training(self):
+        opts = self.opts
+        self.init_dataset()
+        self.define_model()
+        self.define_criterion()
+        self.model = self._wrap(self.model)
+        if self._second_optimizer():
+            self.part_basis_generator = self._wrap(self.part_basis_generator)
+
+        def make(params):
+            if opts.use_sgd:
+                return torch.optim.SGD(params, lr=opts.learning_rate, momentum=opts.beta1)
+            return torch.optim.Adam(params, lr=opts.learning_rate, betas=(opts.beta1, 0.999))
+
+        self.optimizer = make(self.model.parameters())
+        if self._second_optimizer():
+            self.optimizer_2 = make(self.part_basis_generator.parameters())
+
+    # ---- loop ------------------------------------------------------------------------------
+    def reduce_scalars(self, scalars):
+        """Mean over ranks of a dict of python floats (one small all-reduce)."""
+        if not self.env.distributed:
+            return scalars
+        keys = sorted(scalars)
+        t = torch.tensor([float(scalars[k]) for k in keys], dtype=torch.float64, device=self.device)
+        dist.all_reduce(t)
+        t /= self.env.world_size
+        return {k: float(v) for k, v in zip(keys, t.tolist())}
+
+    def train_step(self, batch, total_steps, scaler):
+        opts = self.opts
+        self.set_input(batch)
+        if self.invalid_batch:
+            return False
+        self.optimizer.zero_grad(set_to_none=True)
+        if self._second_optimizer():
+            self.optimizer_2.zero_grad(set_to_none=True)
+        use_amp = self.device.type == 'cuda' and bool(getattr(opts, 'amp', 1))
+        with torch.autocast(device_type=self.device.type, enabled=use_amp):
+            self.forward(total_steps)
+        # the reference's smoothed loss (:194), kept on the device: no host sync per step
+        self.smoothed_total_loss = self.smoothed_total_loss * 0.99 + 0.01 * self.total_loss.detach().float()
+        scaler.scale(self.total_loss).backward()
+        clip = getattr(opts, 'grad_clip', 0.1)
+        scaler.unscale_(self.optimizer)
+        torch.nn.utils.clip_grad_norm_(self.model.parameters(), clip)
+        scaler.step(self.optimizer)
+        if self._second_optimizer():
+            scaler.unscale_(self.optimizer_2)
+            torch.nn.utils.clip_grad_norm_(self.part_basis_generator.parameters(), clip)
+            scaler.step(self.optimizer_2)
+        scaler.update()
+        return True
+
+    def train(self):
+        opts = self.opts
+        self.smoothed_total_loss = 0.0
+        dataset_size = len(self.dataloader)
+        total_steps = dataset_size * opts.num_pretrain_epochs
+        use_amp = self.device.type == 'cuda' and bool(getattr(opts, 'amp', 1))
+        scaler = torch.amp.GradScaler(self.device.type, enabled=use_amp)
+        frac = getattr(opts, 'epoch_fraction', 0.1)
+        self.images_seen = 0
+        t_log = time.time()
+        for epoch in range(opts.num_pretrain_epochs, opts.num_epochs):
+            sampler = getattr(self.dataloader, 'sampler', None)
+            if hasattr(sampler, 'set_epoch'):
+                sampler.set_epoch(epoch)
+            epoch_iter = 0
+            for i, batch in enumerate(self.dataloader):
+                if self.train_step(batch, total_steps, scaler):
+                    self.images_seen += opts.batch_size * self.env.world_size
+                total_steps += 1
+                epoch_iter += 1
+                if opts.print_scalars and total_steps % opts.print_freq == 0:
+                    # the only host sync: once per print_freq steps (the reference syncs every step)
+                    scalars = self.reduce_scalars(self.get_current_scalars())
+                    if self.env.is_main:
+                        dt = time.time() - t_log
+                        rate = opts.print_freq * opts.batch_size * self.env.world_size / max(dt, 1e-9)
+                        msg = ', '.join('%s: %.4g' % kv for kv in sorted(scalars.items()))
+                        print('(epoch: %d, iters: %d, %.1f img/s over %d rank(s)) %s'
+                              % (epoch, epoch_iter, rate, self.env.world_size, msg), flush=True)
+                    t_log = time.time()
+                if total_steps % opts.save_latest_freq == 0:
+                    self.save('latest')
+                    if self._second_optimizer():
+                        self.save_basis('latest')
+                if total_steps == opts.num_iter:
+                    return total_steps
+                if frac < 1.0 and i / dataset_size > frac:
+                    break
+            if (epoch + 1) % opts.save_epoch_freq == 0:
+                self.save('latest')
+                self.save(epoch + 1)
+                if self._second_optimizer():
+                    self.save_basis('latest')
+                    self.save_basis(epoch + 1)
+        return total_steps

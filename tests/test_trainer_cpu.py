@@ -1,0 +1,133 @@
+"""CPU tests of the trainer loop and its data-parallel path (gloo, world_size 2).
+
+The hot-path kernels are GPU-only, so the model here is a plain-torch toy: what is checked
+is the plumbing added to the reference's single-process Trainer -- rank set-up, DDP gradient
+averaging (every rank ends with identical weights, equal to a single-process run on the
+union batch), the sharded sampler, rank-0-only snapshots, scalar reduction.
+"""
+import argparse
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "single-view-3d-reconstruction_amd")
+
+
+def _opts(tmp, **kw):
+    from nnutils import train_utils
+    o = train_utils.add_training_flags().parse_args([])
+    o.checkpoint_dir, o.name = tmp, "t"
+    o.num_epochs, o.print_freq, o.save_epoch_freq, o.epoch_fraction = 2, 2, 1, 1.0
+    o.learning_rate, o.batch_size, o.grad_clip = 1e-2, 4, 1e9
+    for k, v in kw.items():
+        setattr(o, k, v)
+    return o
+
+
+def _make_trainer(opts, env, n=16):
+    from nnutils import train_utils
+
+    class Toy(train_utils.Trainer):
+        def init_dataset(self):
+            g = torch.Generator().manual_seed(123)
+            x = torch.randn(n, 6, generator=g)
+            y = x @ torch.arange(6.0)[:, None] + 0.1
+            ds = torch.utils.data.TensorDataset(x, y)
+            sampler = self.make_sampler(ds, shuffle=False)
+            self.dataloader = torch.utils.data.DataLoader(ds, batch_size=self.opts.batch_size,
+                                                          sampler=sampler, shuffle=False, drop_last=True)
+
+        def define_model(self):
+            torch.manual_seed(7)                     # identical initial weights on every rank
+            self.model = torch.nn.Sequential(torch.nn.Linear(6, 8), torch.nn.Tanh(), torch.nn.Linear(8, 1))
+            self.part_basis_generator = torch.nn.Linear(1, 1, bias=False)
+
+        def define_criterion(self):
+            self.crit = torch.nn.MSELoss()
+
+        def set_input(self, batch):
+            self.x, self.y = (t.to(self.device) for t in batch)
+
+        def forward(self, total_steps=0):
+            self.total_loss = self.crit(self.part_basis_generator(self.model(self.x)), self.y)
+
+    return Toy(opts, env)
+
+
+def _worker(rank, world, port, tmp, out):
+    sys.path[:0] = [ROOT, PKG]
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from nnutils import train_utils
+    env = train_utils.init_distributed(backend="gloo")
+    assert env.world_size == world and env.rank == rank and env.device.type == "cpu"
+    t = _make_trainer(_opts(tmp, seg_train=1, batch_size=4), env)
+    t.init_training()
+    assert isinstance(t.model, torch.nn.parallel.DistributedDataParallel)
+    assert isinstance(t.part_basis_generator, torch.nn.parallel.DistributedDataParallel)
+    steps = t.train()
+    sc = t.reduce_scalars({"rank": float(rank)})
+    state = {k: v.clone() for k, v in train_utils.unwrap(t.model).state_dict().items()}
+    torch.save({"state": state, "steps": steps, "mean_rank": sc["rank"], "seen": t.images_seen,
+                "w2": train_utils.unwrap(t.part_basis_generator).weight.detach().clone()},
+               os.path.join(out, "rank%d.pt" % rank))
+    torch.distributed.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def test_two_rank_gloo_matches_single_process(tmp_path):
+    tmp = str(tmp_path)
+    mp.spawn(_worker, args=(2, _free_port(), tmp, tmp), nprocs=2, join=True)
+    r0 = torch.load(os.path.join(tmp, "rank0.pt"), weights_only=True)
+    r1 = torch.load(os.path.join(tmp, "rank1.pt"), weights_only=True)
+    for k in r0["state"]:
+        assert torch.equal(r0["state"][k], r1["state"][k]), k          # ranks stay in lockstep
+    assert torch.equal(r0["w2"], r1["w2"])
+    assert r0["steps"] == r1["steps"] == 4 and r0["mean_rank"] == 0.5
+    assert r0["seen"] == 4 * 4 * 2                                     # steps x batch x ranks
+    # rank 0 alone wrote the snapshots, from the unwrapped module (no 'module.' prefix)
+    files = sorted(os.listdir(os.path.join(tmp, "t")))
+    assert "pred_net_latest.pth" in files and "part_basis_net_2.pth" in files and "opts.log" in files
+    saved = torch.load(os.path.join(tmp, "t", "pred_net_2.pth"), weights_only=True)
+    assert set(saved) == set(r0["state"]) and all(torch.equal(saved[k], r0["state"][k]) for k in saved)
+
+    # single process on the union batch: DistributedSampler(shuffle=False) deals samples
+    # round-robin, so two ranks x batch 4 see the same 8 samples per step as one x batch 8
+    from nnutils import train_utils
+    single = _make_trainer(_opts(os.path.join(tmp, "single"), seg_train=1, batch_size=8), train_utils.DistEnv())
+    single.init_training()
+    assert single.train() == 4
+    for k, v in single.model.state_dict().items():
+        assert torch.allclose(v, r0["state"][k], rtol=1e-5, atol=1e-6), k
+
+
+def test_single_process_loop_semantics(tmp_path):
+    from nnutils import train_utils
+    o = _opts(str(tmp_path), num_epochs=3, epoch_fraction=0.1, num_iter=0, save_epoch_freq=2)
+    t = _make_trainer(o, train_utils.DistEnv(), n=80)           # 20 batches per epoch
+    t.init_training()
+    assert not hasattr(t, "optimizer_2")                          # seg_train off: one optimizer
+    steps = t.train()
+    assert steps == 3 * 4                                         # epoch cut once i/20 > 0.1 -> 4 iterations
+    assert sorted(os.listdir(t.save_dir)) == ["opts.log", "pred_net_2.pth", "pred_net_latest.pth"]
+    o.num_iter = 5
+    t2 = _make_trainer(o, train_utils.DistEnv(), n=80)
+    t2.init_training()
+    assert t2.train() == 5
+    t2.load_network(t2.model, "pred", "latest")                   # round trip through the snapshot
+    t2.invalid_batch = True
+    before = [p.clone() for p in t2.model.parameters()]
+    t2.train_step(next(iter(t2.dataloader)), 0, torch.amp.GradScaler("cpu", enabled=False))
+    assert all(torch.equal(a, b) for a, b in zip(before, t2.model.parameters()))
