@@ -27,6 +27,23 @@
 
 #include "sv3d_hip.h"
 
+#ifdef SV3D_TRACE
+// Diagnostic build only: per-workgroup start / end stamps and phase stamps of the forward kernel.
+__device__ unsigned long long g_trace[4 * 16384];
+__device__ unsigned long long g_phase[8 * 4096];
+#define SV3D_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 4096) g_phase[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+extern "C" int sv3d_debug_read_trace(void *host_out, size_t bytes)
+{
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_trace), bytes, 0, hipMemcpyDeviceToHost);
+}
+extern "C" int sv3d_debug_read_phase(void *host_out, size_t bytes)
+{
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_phase), bytes, 0, hipMemcpyDeviceToHost);
+}
+#else
+#define SV3D_STAMP(i) do { } while (0)
+#endif
+
 namespace {
 
 constexpr int kThreads = 256;
@@ -37,7 +54,7 @@ constexpr int kTile = 16;         // tile side in raster pixels
 #define SV3D_LIST_CAP 128
 #endif
 constexpr int kListCap = SV3D_LIST_CAP;   // faces staged in LDS at a time (128 B each)
-constexpr int kMaskCap = 256;             // 64-face hit masks per binning pass (16384 faces)
+constexpr int kRecPad4 = kRec4 + 1;       // LDS record stride (144 B): lane-strided reads are conflict free
 
 struct DevParams {
     int B, F, S, aa, mode, R, double_side;
@@ -140,8 +157,9 @@ __device__ inline PairGeom pair_geom(const FaceRec &r, float xp, float yp, const
     g.dx = g.k0 ? d0x : (g.k1 ? d1x : d2x);
     g.dy = g.k0 ? d0y : (g.k1 ? d1y : d2y);
     g.inside = (g.w0 > 0.f) && (g.w1 > 0.f) && (g.w2 > 0.f);
-    const bool in_box = !(xp > r.bx1 || xp < r.bx0 || yp > r.by1 || yp < r.by0);
-    g.act = in_box && (g.inside || g.d2 < P.threshold);
+    // A pixel outside the face's cull box (bbox widened by sqrt(threshold)) is farther than
+    // sqrt(threshold) from the triangle, so the distance test alone implements both culls.
+    g.act = g.inside || g.d2 < P.threshold;
     // exp(-x) with x = +-d2/sigma; D = 1/(1+exp(-x)); 1-D = exp(-x) D (no cancellation)
     const float e = ex2((g.inside ? g.d2 : -g.d2) * P.neg_l2e_over_sigma);
     const float D = rcp(1.f + e);
@@ -249,6 +267,25 @@ __device__ inline void unpack_box(uint2 b, int &col0, int &col1, int &row0, int 
     row1 = (int)(short)(b.y >> 16);
 }
 
+// Inclusive prefix sum over the 64 lanes (row shifts inside each row of 16 lanes, then the row
+// totals are broadcast into the following rows).
+template <int CTRL, int ROW_MASK>
+__device__ inline int dpp_add_i(int v)
+{
+    return v + __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xf, true);
+}
+
+__device__ inline int wave_inclusive_scan(int v)
+{
+    v = dpp_add_i<0x111, 0xf>(v);       // row_shr:1
+    v = dpp_add_i<0x112, 0xf>(v);       // row_shr:2
+    v = dpp_add_i<0x114, 0xf>(v);       // row_shr:4
+    v = dpp_add_i<0x118, 0xf>(v);       // row_shr:8
+    v = dpp_add_i<0x142, 0xa>(v);       // row_bcast:15 into rows 1 and 3
+    v = dpp_add_i<0x143, 0xc>(v);       // row_bcast:31 into rows 2 and 3
+    return v;
+}
+
 // ------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------
@@ -257,23 +294,27 @@ __global__ __launch_bounds__(kThreads) void raster_forward_kernel(
     DevParams P, const float4 *__restrict__ rec, const uint2 *__restrict__ pbox,
     const float *__restrict__ tex, float *__restrict__ rgba, float *__restrict__ saved)
 {
-    __shared__ float4 s_rec[kListCap * kRec4];
+    __shared__ float4 s_rec[kListCap * kRecPad4];
     __shared__ int s_ids[kListCap];
-    __shared__ unsigned long long s_mask[kMaskCap];
-    __shared__ int s_moff[kMaskCap];
-    __shared__ int s_total;
+    __shared__ unsigned long long s_mask[64];
 
     // Workgroup id -> (image, tile) with the image index fastest: workgroups that land on one
     // CU (ids a multiple of the CU count apart) then come from tile positions spread over the
     // screen, instead of the same position of every image, which balances silhouette-ring tiles
     // (many faces) against empty corners.
+#ifdef SV3D_TRACE
+    const unsigned long long trace_t0 = __builtin_amdgcn_s_memrealtime();
+#endif
     const int tiles_x = (P.S + kTile - 1) / kTile;
     const int b = blockIdx.x % P.B;
     const int tile = blockIdx.x / P.B;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int S = P.S, F = P.F;
-    const int tile_c0 = (tile % tiles_x) * kTile, tile_r0 = (tile / tiles_x) * kTile;
+    // ... and every tile row is rotated by 5 more columns than the row above, so that the tiles
+    // one CU receives do not share a screen column either.
+    const int tile_y = tile / tiles_x;
+    const int tile_c0 = ((tile % tiles_x + 5 * tile_y) % tiles_x) * kTile, tile_r0 = tile_y * kTile;
     // lane -> pixel of the wave's 8x8 block; lanes 4q..4q+3 form the 2x2 quad q
     const int quad = lane >> 2, sub = lane & 3;
     const int blk_c0 = tile_c0 + (wave & 1) * 8, blk_r0 = tile_r0 + (wave >> 1) * 8;
@@ -291,29 +332,58 @@ __global__ __launch_bounds__(kThreads) void raster_forward_kernel(
     const float zref = ((const float *)rec_b)[27];
     const float c0shift = (P.far_plane - zref) * P.inv_range;
 
+#ifdef SV3D_TRACE
+    int trace_visits = 0;
+#endif
     float A = 1.f;                              // prod (1 - D)
     float m = P.eps - c0shift;                  // running softmax maximum, shifted by c0shift
     float ssum = P.ssum0;
     float C0 = P.bg0 * ssum, C1 = P.bg1 * ssum, C2 = P.bg2 * ssum;
 
+    // Conservative per-(block, face) test run lane-parallel over list entries: the block can only
+    // hold an active pixel if it overlaps the face's cull box AND no edge line has the whole
+    // block on its outer side at more than the cull distance (the triangle lies on the inner
+    // side of each of its edge lines).
+    const float bcx = 0.5f * (bxa + bxb), bcy = 0.5f * (bya + byb);
+    const float bhx = 0.5f * (bxb - bxa), bhy = 0.5f * (byb - bya);
+    auto block_may_touch = [&](const float4 *r) -> bool {
+        const float4 bb = r[4];
+        if (bxa > bb.y || bxb < bb.x || bya > bb.w || byb < bb.z) return false;
+        const float4 q0 = r[0], q1 = r[1], q2 = r[2], q3 = r[3];
+        const float sgn = q3.w > 0.f ? 1.f : -1.f;              // orientation (sign of 1/det)
+        // edge k: start point, direction, 1/|e|^2
+        const float px[3] = {q0.x, q0.z, q1.x}, py[3] = {q0.y, q0.w, q1.y};
+        const float ex[3] = {q1.z, q2.x, q2.z}, ey[3] = {q1.w, q2.y, q2.w};
+        const float il[3] = {q3.x, q3.y, q3.z};
+        bool ok = true;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float c = ey[k] * (px[k] - bcx) - ex[k] * (py[k] - bcy);     // edge function at the centre
+            const float v = sgn * c + fabsf(ey[k]) * bhx + fabsf(ex[k]) * bhy;  // its maximum over the block
+            ok = ok && !(v < 0.f && v * v * il[k] > P.threshold);
+        }
+        return ok;
+    };
+
     auto process_list = [&](int n) {
+        SV3D_STAMP(3);
         for (int i = threadIdx.x; i < n * kRec4; i += kThreads)
-            s_rec[i] = rec_b[(size_t)s_ids[i / kRec4] * kRec4 + (i % kRec4)];
+            s_rec[(i / kRec4) * kRecPad4 + (i % kRec4)] = rec_b[(size_t)s_ids[i / kRec4] * kRec4 + (i % kRec4)];
         __syncthreads();
+        SV3D_STAMP(4);
         for (int j0 = 0; j0 < n; j0 += 64) {
             const int j = j0 + lane;
-            bool hit = false;
-            if (j < n) {
-                const float4 bb = s_rec[j * kRec4 + 4];
-                hit = !(bxa > bb.y || bxb < bb.x || bya > bb.w || byb < bb.z);
-            }
+            const bool hit = j < n && block_may_touch(&s_rec[min(j, n - 1) * kRecPad4]);
             unsigned long long mask = __ballot(hit);
             while (mask) {
                 const int jj = j0 + __builtin_ctzll(mask);
                 mask &= mask - 1;
-                const FaceRec r = load_rec(&s_rec[jj * kRec4]);
+                const FaceRec r = load_rec(&s_rec[jj * kRecPad4]);
                 const PairGeom g = pair_geom(r, xp, yp, P);
                 A *= g.omD;
+#ifdef SV3D_TRACE
+                ++trace_visits;
+#endif
                 if (MODE != SV3D_TEX_NONE) {
                     const PairDepth d = pair_depth(r, g, P);
                     float k0 = 0.f, k1 = 0.f, k2 = 0.f;
@@ -347,25 +417,26 @@ __global__ __launch_bounds__(kThreads) void raster_forward_kernel(
     };
 
     // ---- binning: the faces whose pixel box touches this tile, in face order ----------------
-    // One pass over the compact box array; a wave's loads are independent, so their latencies
-    // overlap.  The hit bits of 64 consecutive faces are kept as one 64-bit mask in LDS, an
-    // exclusive scan of the mask popcounts gives every hit its list position, and the list is
-    // consumed in windows of kListCap faces.
+    // One pass over the compact box array, eight independent loads in flight per wave.  The hit
+    // bits of 64 consecutive faces are kept as one 64-bit mask in LDS; every wave then scans the
+    // mask popcounts for itself (DPP prefix sum, no second barrier), which gives each hit its
+    // list position, and the list is consumed in windows of kListCap faces.
     const int tc1 = tile_c0 + kTile - 1, tr1 = tile_r0 + kTile - 1;
     const unsigned long long lane_lt = (1ull << lane) - 1ull;
-    for (int fbase = 0; fbase < F; fbase += kMaskCap * 64) {
-        const int nmask = (min(F - fbase, kMaskCap * 64) + 63) >> 6;
-        for (int m0 = wave; m0 < nmask; m0 += 16) {      // four masks per wave per trip
-            uint2 bx[4];
+    SV3D_STAMP(0);
+    for (int fbase = 0; fbase < F; fbase += 64 * 64) {
+        const int nmask = (min(F - fbase, 64 * 64) + 63) >> 6;      // at most 64 masks per pass
+        for (int m0 = wave; m0 < nmask; m0 += 32) {                 // eight masks per wave per trip
+            uint2 bx[8];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {                // four independent loads in flight
+            for (int k = 0; k < 8; ++k) {
                 const int f = fbase + (m0 + 4 * k) * 64 + lane;
                 bx[k] = f < F ? pbox_b[f] : make_uint2(0xffff7fffu, 0xffff7fffu);   // empty box
             }
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
+            for (int k = 0; k < 8; ++k) {
                 const int mi = m0 + 4 * k;
-                if (mi < nmask) {                        // wave-uniform
+                if (mi < nmask) {                                   // wave-uniform
                     int c0, c1, r0, r1;
                     unpack_box(bx[k], c0, c1, r0, r1);
                     const bool hit = !(c1 < tile_c0 || c0 > tc1 || r1 < tile_r0 || r0 > tr1);
@@ -375,35 +446,20 @@ __global__ __launch_bounds__(kThreads) void raster_forward_kernel(
             }
         }
         __syncthreads();
-        if (wave == 0) {                        // lane l scans masks 4l .. 4l+3
-            int c[4], sum = 0;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int mi = 4 * lane + k;
-                c[k] = mi < nmask ? __popcll(s_mask[mi]) : 0;
-                sum += c[k];
-            }
-            int incl = sum;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const int t = __shfl_up(incl, d);
-                if (lane >= d) incl += t;
-            }
-            int run = incl - sum;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                s_moff[4 * lane + k] = run;
-                run += c[k];
-            }
-            if (lane == 63) s_total = incl;
-        }
-        __syncthreads();
-        const int total = s_total;
+        SV3D_STAMP(1);
+        // lane l holds mask l; exclusive prefix of the popcounts over the wave
+        const unsigned long long my_mask = lane < nmask ? s_mask[lane] : 0ull;
+        const int my_cnt = __popcll(my_mask);
+        const int incl = wave_inclusive_scan(my_cnt);
+        const int total = __builtin_amdgcn_readlane(incl, 63);
+        const int excl = incl - my_cnt;
+        SV3D_STAMP(2);
         for (int win = 0; win < total; win += kListCap) {
             for (int mi = wave; mi < nmask; mi += 4) {
                 const unsigned long long mask = s_mask[mi];
+                const int off = __builtin_amdgcn_readlane(excl, mi);
                 if ((mask >> lane) & 1ull) {
-                    const int pos = s_moff[mi] + __popcll(mask & lane_lt) - win;
+                    const int pos = off + __popcll(mask & lane_lt) - win;
                     if (pos >= 0 && pos < kListCap) s_ids[pos] = fbase + mi * 64 + lane;
                 }
             }
@@ -414,6 +470,7 @@ __global__ __launch_bounds__(kThreads) void raster_forward_kernel(
     }
 
     // epilogue
+    SV3D_STAMP(5);
     float o0, o1, o2;
     if (MODE != SV3D_TEX_NONE) {
         const float is = 1.f / ssum;
@@ -456,6 +513,20 @@ __global__ __launch_bounds__(kThreads) void raster_forward_kernel(
         rgba[o + 2 * plane] = o2;
         rgba[o + 3 * plane] = o3;
     }
+    SV3D_STAMP(6);
+#ifdef SV3D_TRACE
+    if (lane == 0 && blockIdx.x < 4096) {
+        unsigned hwid;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        unsigned long long *t = g_trace + ((size_t)blockIdx.x * 4 + wave) * 4;
+        t[0] = trace_t0;
+        t[1] = __builtin_amdgcn_s_memrealtime();
+        t[2] = ((unsigned long long)xcc << 32) | hwid;
+        t[3] = (unsigned long long)trace_visits;
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------
@@ -752,12 +823,13 @@ int raster_forward_impl(const sv3d_raster_params *p, const float *face_vertices,
     dim3 grid((unsigned)tiles * tiles * d.B), block(kThreads);
     float *saved = static_cast<float *>(pixel_saved);
     if (ev_start) (void)hipEventRecord(ev_start, s);
+#define SV3D_FWD_KERNEL raster_forward_kernel
     if (d.mode == SV3D_TEX_NONE)
-        hipLaunchKernelGGL(raster_forward_kernel<SV3D_TEX_NONE>, grid, block, 0, s, d, rec, pbox, textures, rgba_out, saved);
+        hipLaunchKernelGGL(SV3D_FWD_KERNEL<SV3D_TEX_NONE>, grid, block, 0, s, d, rec, pbox, textures, rgba_out, saved);
     else if (d.mode == SV3D_TEX_SURFACE)
-        hipLaunchKernelGGL(raster_forward_kernel<SV3D_TEX_SURFACE>, grid, block, 0, s, d, rec, pbox, textures, rgba_out, saved);
+        hipLaunchKernelGGL(SV3D_FWD_KERNEL<SV3D_TEX_SURFACE>, grid, block, 0, s, d, rec, pbox, textures, rgba_out, saved);
     else
-        hipLaunchKernelGGL(raster_forward_kernel<SV3D_TEX_VERTEX>, grid, block, 0, s, d, rec, pbox, textures, rgba_out, saved);
+        hipLaunchKernelGGL(SV3D_FWD_KERNEL<SV3D_TEX_VERTEX>, grid, block, 0, s, d, rec, pbox, textures, rgba_out, saved);
     if (ev_stop) (void)hipEventRecord(ev_stop, s);
     return launch_status();
 }
