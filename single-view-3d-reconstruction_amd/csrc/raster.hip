@@ -587,10 +587,13 @@ __device__ inline float wave_sum(float v)
     return (a + b) + (c + d);
 }
 
+// `prep`: colour modes read the folded per-pixel gradient written by raster_prep_kernel;
+// silhouette mode folds on the fly (g_alpha * A needs one value of each array), which saves a
+// launch: there `prep` is the saved A array and `galpha` the alpha plane of the incoming gradient.
 template <int MODE>
 __global__ __launch_bounds__(kThreads) void raster_backward_kernel(
     DevParams P, const float4 *__restrict__ rec, const uint2 *__restrict__ pbox,
-    const float *__restrict__ tex, const float *__restrict__ prep,
+    const float *__restrict__ tex, const float *__restrict__ prep, const float *__restrict__ galpha,
     float *__restrict__ gfv, float *__restrict__ gtex)
 {
     extern __shared__ float s_dyn[];            // SURFACE: 4 x (R*R*3) texel accumulators
@@ -630,6 +633,9 @@ __global__ __launch_bounds__(kThreads) void raster_backward_kernel(
     float xp0, yp0;
     pixel_centre(col0, row0, S, xp0, yp0);
     const float *prep_b = prep + (size_t)b * S * S * (MODE == SV3D_TEX_NONE ? 1 : 6);
+    const int H = S / P.aa;
+    const float *galpha_b = MODE == SV3D_TEX_NONE ? galpha + ((size_t)b * 4 + 3) * H * H : nullptr;
+    const float gscale = P.aa == 2 ? 0.25f : 1.f;
     for (int base = 0; base < npix; base += 64) {
         const int idx = base + lane;
         const bool valid = idx < npix;
@@ -641,14 +647,16 @@ __global__ __launch_bounds__(kThreads) void raster_backward_kernel(
         if (!valid) { rx_f = 0.f; ry_f = 0.f; }
         const float xp = fmaf(rx_f, step, xp0);
         const float yp = fmaf(-ry_f, step, yp0);
-        const unsigned pix = (unsigned)(row0 + (int)ry_f) * (unsigned)S + (unsigned)(col0 + (int)rx_f);
+        const unsigned prow = (unsigned)(row0 + (int)ry_f), pcol = (unsigned)(col0 + (int)rx_f);
+        const unsigned pix = prow * (unsigned)S + pcol;
 
         PairGeom g = pair_geom(r, xp, yp, P);
         const bool act = valid && g.act;
         float P0;
         float G0 = 0.f, G1 = 0.f, G2 = 0.f, Rr = 0.f, mfin = 0.f;
         if (MODE == SV3D_TEX_NONE) {
-            P0 = prep_b[pix];
+            const unsigned gpix = P.aa == 2 ? (prow >> 1) * (unsigned)H + (pcol >> 1) : pix;
+            P0 = prep_b[pix] * (galpha_b[gpix] * gscale);
         } else {
             const float2 *pp = (const float2 *)(prep_b + pix * 6u);
             const float2 a0 = pp[0], a1 = pp[1], a2 = pp[2];
@@ -781,6 +789,11 @@ int make_dev_params(const sv3d_raster_params *p, DevParams &d)
 
 inline size_t rec_floats(const DevParams &d) { return (size_t)d.B * d.F * kRec; }
 inline int saved_per_pixel(const DevParams &d) { return d.mode == SV3D_TEX_NONE ? 1 : 6; }
+inline size_t backward_ws_need(const DevParams &d)
+{
+    // the silhouette backward folds the incoming gradient on the fly and needs no scratch
+    return d.mode == SV3D_TEX_NONE ? 0 : (size_t)d.B * d.S * d.S * 6 * sizeof(float);
+}
 
 inline int launch_status()
 {
@@ -798,7 +811,7 @@ extern "C" int sv3d_raster_sizes(const sv3d_raster_params *p, size_t *face_rec_b
     const size_t pix = (size_t)d.B * d.S * d.S * saved_per_pixel(d) * sizeof(float);
     if (face_rec_bytes) *face_rec_bytes = rec_floats(d) * sizeof(float) + (size_t)d.B * d.F * sizeof(uint2);
     if (pixel_saved_bytes) *pixel_saved_bytes = pix;
-    if (backward_ws_bytes) *backward_ws_bytes = pix;
+    if (backward_ws_bytes) *backward_ws_bytes = backward_ws_need(d);
     return SV3D_OK;
 }
 
@@ -842,11 +855,10 @@ int raster_backward_impl(const sv3d_raster_params *p, const float *textures, con
     DevParams d;
     const int st = make_dev_params(p, d);
     if (st != SV3D_OK) return st;
-    if (!face_rec || !pixel_saved || !grad_rgba || !grad_face_vertices || !workspace)
-        return SV3D_ERR_INVALID_ARG;
+    if (!face_rec || !pixel_saved || !grad_rgba || !grad_face_vertices) return SV3D_ERR_INVALID_ARG;
     if (d.mode != SV3D_TEX_NONE && !textures) return SV3D_ERR_INVALID_ARG;
-    const size_t need = (size_t)d.B * d.S * d.S * saved_per_pixel(d) * sizeof(float);
-    if (workspace_bytes < need) return SV3D_ERR_WORKSPACE;
+    const size_t need = backward_ws_need(d);
+    if (need > 0 && (!workspace || workspace_bytes < need)) return SV3D_ERR_WORKSPACE;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const float4 *rec = static_cast<const float4 *>(face_rec);
     const uint2 *pbox = reinterpret_cast<const uint2 *>(static_cast<const float *>(face_rec) + rec_floats(d));
@@ -856,21 +868,20 @@ int raster_backward_impl(const sv3d_raster_params *p, const float *textures, con
     const dim3 pgrid((unsigned)((npix + kThreads - 1) / kThreads)), block(kThreads);
     const dim3 fgrid((d.B * d.F + 3) / 4);
     if (d.mode == SV3D_TEX_NONE) {
-        hipLaunchKernelGGL(raster_prep_kernel<SV3D_TEX_NONE>, pgrid, block, 0, s, d, saved, grad_rgba, prep);
         if (ev_start) (void)hipEventRecord(ev_start, s);
         hipLaunchKernelGGL(raster_backward_kernel<SV3D_TEX_NONE>, fgrid, block, 0, s, d, rec, pbox,
-                           textures, prep, grad_face_vertices, (float *)nullptr);
+                           textures, saved, grad_rgba, grad_face_vertices, (float *)nullptr);
     } else if (d.mode == SV3D_TEX_SURFACE) {
         const size_t lds = (size_t)4 * d.R * d.R * 3 * sizeof(float);
         hipLaunchKernelGGL(raster_prep_kernel<SV3D_TEX_SURFACE>, pgrid, block, 0, s, d, saved, grad_rgba, prep);
         if (ev_start) (void)hipEventRecord(ev_start, s);
         hipLaunchKernelGGL(raster_backward_kernel<SV3D_TEX_SURFACE>, fgrid, block, lds, s, d, rec, pbox,
-                           textures, prep, grad_face_vertices, grad_textures);
+                           textures, prep, (const float *)nullptr, grad_face_vertices, grad_textures);
     } else {
         hipLaunchKernelGGL(raster_prep_kernel<SV3D_TEX_VERTEX>, pgrid, block, 0, s, d, saved, grad_rgba, prep);
         if (ev_start) (void)hipEventRecord(ev_start, s);
         hipLaunchKernelGGL(raster_backward_kernel<SV3D_TEX_VERTEX>, fgrid, block, 0, s, d, rec, pbox,
-                           textures, prep, grad_face_vertices, grad_textures);
+                           textures, prep, (const float *)nullptr, grad_face_vertices, grad_textures);
     }
     if (ev_stop) (void)hipEventRecord(ev_stop, s);
     return launch_status();

@@ -66,6 +66,7 @@ def main():
         rec_b, saved_b, ws_b = L.raster_sizes(p)
         f32 = dict(dtype=torch.float32, device=dev)
         rgba = torch.empty((B, 4, img, img), **f32)
+        ws_b = max(ws_b, saved_b)                 # older builds want scratch in every mode
         rec, saved, ws = (torch.empty(n // 4, **f32) for n in (rec_b, saved_b, ws_b))
         gfv = torch.empty_like(fv)
         gtex = torch.empty_like(tex) if tex is not None else None
