@@ -24,6 +24,7 @@ namespace {
 constexpr int kThreads = 256;
 constexpr int kWaves = 4;
 constexpr int kTile = 1024;          // candidates staged per LDS tile (16 KiB)
+constexpr int kGroup = 8;            // candidates per group minimum
 
 template <int Q>
 __global__ __launch_bounds__(kThreads) void chamfer_nn_kernel(
@@ -73,7 +74,48 @@ __global__ __launch_bounds__(kThreads) void chamfer_nn_kernel(
         const int quarter = (tn + kWaves - 1) / kWaves;
         const int jb = wave * quarter;
         const int je = min(jb + quarter, tn);
-        for (int j = jb; j < je; ++j) {
+        // Candidates are taken in groups of kGroup: the group minimum costs half a v_min3 per
+        // distance, and the compare / select pair that a running argmin needs per distance is
+        // only paid when some lane's minimum improves (ever rarer as the scan proceeds).  The
+        // result is the one the plain scan gives: a group only wins with a strictly smaller
+        // distance, and inside the group the first index attaining the minimum is taken.
+        int j = jb;
+        for (; j + kGroup <= je; j += kGroup) {
+            float d[Q][kGroup];
+#pragma unroll
+            for (int u = 0; u < kGroup; ++u) {
+                const float4 c = s_pts[j + u];
+#pragma unroll
+                for (int k = 0; k < Q; ++k) {
+                    const float dx = c.x - qx[k];
+                    const float dy = c.y - qy[k];
+                    const float dz = c.z - qz[k];
+                    d[k][u] = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+                }
+            }
+            bool better = false;
+            float gm[Q];
+#pragma unroll
+            for (int k = 0; k < Q; ++k) {
+                const float m1 = fminf(fminf(d[k][0], d[k][1]), d[k][2]);
+                const float m2 = fminf(fminf(d[k][3], d[k][4]), d[k][5]);
+                gm[k] = fminf(fminf(d[k][6], d[k][7]), fminf(m1, m2));
+                better = better || (gm[k] < best[k]);
+            }
+            if (__any(better)) {
+#pragma unroll
+                for (int k = 0; k < Q; ++k) {
+                    if (gm[k] < best[k]) {
+                        best[k] = gm[k];
+                        int u0 = kGroup - 1;
+#pragma unroll
+                        for (int u = kGroup - 2; u >= 0; --u) u0 = d[k][u] == gm[k] ? u : u0;
+                        bi[k] = t0 + j + u0;
+                    }
+                }
+            }
+        }
+        for (; j < je; ++j) {                       // tail of the quarter
             const float4 c = s_pts[j];
             const int gj = t0 + j;
 #pragma unroll
