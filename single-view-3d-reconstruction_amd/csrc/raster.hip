@@ -626,9 +626,11 @@ __global__ __launch_bounds__(kThreads) void raster_backward_kernel(
 #pragma unroll
     for (int i = 0; i < 9; ++i) { acc[i] = 0.f; tacc[i] = 0.f; }
 
-    // Lanes enumerate the box row-major, 64 pixels per step.  Index arithmetic in fp32 is
-    // exact here (a box holds < 2^24 pixels because S <= 4096).
-    const float bw_f = (float)bw;
+    // Lanes enumerate the box row-major, 64 pixels per step.  (rx, ry) = position inside the box,
+    // kept as exact small integers in fp32 and advanced by 64 pixels per step with at most one
+    // row wrap per lane; the per-pixel inputs of step i+1 are requested before step i is
+    // evaluated so that their latency overlaps the arithmetic.
+    const float bw_f = (float)bw, bh_f = (float)bh;
     const float step = 2.f / (float)S;
     float xp0, yp0;
     pixel_centre(col0, row0, S, xp0, yp0);
@@ -636,32 +638,55 @@ __global__ __launch_bounds__(kThreads) void raster_backward_kernel(
     const int H = S / P.aa;
     const float *galpha_b = MODE == SV3D_TEX_NONE ? galpha + ((size_t)b * 4 + 3) * H * H : nullptr;
     const float gscale = P.aa == 2 ? 0.25f : 1.f;
-    for (int base = 0; base < npix; base += 64) {
-        const int idx = base + lane;
-        const bool valid = idx < npix;
-        const float idx_f = (float)idx;
-        float ry_f = floorf((idx_f + 0.5f) * inv_bw);
-        float rx_f = fmaf(-ry_f, bw_f, idx_f);
-        if (rx_f < 0.f) { ry_f -= 1.f; rx_f += bw_f; }
-        if (rx_f >= bw_f) { ry_f += 1.f; rx_f -= bw_f; }
-        if (!valid) { rx_f = 0.f; ry_f = 0.f; }
-        const float xp = fmaf(rx_f, step, xp0);
-        const float yp = fmaf(-ry_f, step, yp0);
-        const unsigned prow = (unsigned)(row0 + (int)ry_f), pcol = (unsigned)(col0 + (int)rx_f);
-        const unsigned pix = prow * (unsigned)S + pcol;
+    const float adv_y = bw > 0 ? (float)(64 / bw) : 0.f, adv_x = bw > 0 ? (float)(64 % bw) : 0.f;
+    float ry_f = floorf(((float)lane + 0.5f) * inv_bw);
+    float rx_f = fmaf(-ry_f, bw_f, (float)lane);
+    if (rx_f < 0.f) { ry_f -= 1.f; rx_f += bw_f; }
+    if (rx_f >= bw_f) { ry_f += 1.f; rx_f -= bw_f; }
 
-        PairGeom g = pair_geom(r, xp, yp, P);
-        const bool act = valid && g.act;
-        float P0;
-        float G0 = 0.f, G1 = 0.f, G2 = 0.f, Rr = 0.f, mfin = 0.f;
+    struct PixIn {
+        float xp, yp, P0, G0, G1, G2, Rr, mfin;
+        bool valid;
+    };
+    auto fetch = [&]() {                            // inputs of the pixel at the current (rx, ry)
+        PixIn in;
+        in.valid = ry_f < bh_f;
+        const float cx = in.valid ? rx_f : 0.f, cy = in.valid ? ry_f : 0.f;
+        in.xp = fmaf(cx, step, xp0);
+        in.yp = fmaf(-cy, step, yp0);
+        const unsigned prow = (unsigned)(row0 + (int)cy), pcol = (unsigned)(col0 + (int)cx);
+        const unsigned pix = prow * (unsigned)S + pcol;
+        in.G0 = in.G1 = in.G2 = in.Rr = in.mfin = 0.f;
         if (MODE == SV3D_TEX_NONE) {
             const unsigned gpix = P.aa == 2 ? (prow >> 1) * (unsigned)H + (pcol >> 1) : pix;
-            P0 = prep_b[pix] * (galpha_b[gpix] * gscale);
+            in.P0 = prep_b[pix];                    // multiplied at the point of use so that
+            in.G0 = galpha_b[gpix];                 // the loads stay in flight across a step
         } else {
             const float2 *pp = (const float2 *)(prep_b + pix * 6u);
             const float2 a0 = pp[0], a1 = pp[1], a2 = pp[2];
-            P0 = a0.x; G0 = a0.y; G1 = a1.x; G2 = a1.y; Rr = a2.x; mfin = a2.y;
+            in.P0 = a0.x; in.G0 = a0.y; in.G1 = a1.x; in.G2 = a1.y; in.Rr = a2.x; in.mfin = a2.y;
         }
+        // advance to the pixel 64 positions further
+        rx_f += adv_x;
+        ry_f += adv_y;
+        const bool wrap = rx_f >= bw_f;
+        rx_f -= wrap ? bw_f : 0.f;
+        ry_f += wrap ? 1.f : 0.f;
+        return in;
+    };
+
+    PixIn nxt;
+    if (npix > 0) nxt = fetch();
+    for (int base = 0; base < npix; base += 64) {
+        const PixIn in = nxt;
+        if (base + 64 < npix) nxt = fetch();        // wave-uniform
+        const float xp = in.xp, yp = in.yp;
+        const bool valid = in.valid;
+        const float G0 = in.G0, G1 = in.G1, G2 = in.G2, Rr = in.Rr, mfin = in.mfin;
+
+        PairGeom g = pair_geom(r, xp, yp, P);
+        const bool act = valid && g.act;
+        const float P0 = MODE == SV3D_TEX_NONE ? in.P0 * (in.G0 * gscale) : in.P0;
         float gx = act ? P0 * g.D : 0.f;        // dL/dx, x = +-d2/sigma, through alpha
 
         if (MODE != SV3D_TEX_NONE) {
