@@ -134,6 +134,23 @@ def cpu_baseline(args, fv0, seconds):
                       % (fv.shape[0], done_px // S, S, dt)}
 
 
+def pmc_traffic(args, kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 counter passes of this same
+    command (profiles/pmc_default_workload.json: FETCH_SIZE and WRITE_SIZE in separate passes,
+    1024-byte units, reads doubled as gfx950 tallies wide coalesced reads at half size).  None when
+    the workload is not the default one or the summary is absent."""
+    default = (args.batch, args.image_size, args.subdivide, args.mode, args.sigma, args.anti_aliasing) == \
+        (8, 256, 3, "none", 1e-4, False)
+    path = os.path.join(ROOT, "profiles", "pmc_default_workload.json")
+    if not default or not os.path.exists(path):
+        return None
+    with open(path) as fh:
+        row = json.load(fh).get(kernel, {})
+    if "hbm_read_bytes_x2" not in row or "hbm_write_bytes" not in row:
+        return None
+    return row["hbm_read_bytes_x2"] + row["hbm_write_bytes"]
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -219,7 +236,8 @@ def main():
     achieved = flop / (ms * 1e-3) / 1e12
     roofline = {"bound": "valu", "kernel": name, "achieved": achieved,
                 "peak": workmodel.FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": achieved / workmodel.FP32_VALU_PEAK_TFLOPS, "traffic": None,
+                "frac": achieved / workmodel.FP32_VALU_PEAK_TFLOPS,
+                "traffic": pmc_traffic(args, name),
                 "avg_kernel_ms": ms, "active_pairs_per_launch": pairs,
                 "flop_per_pair": flop / max(pairs, 1),
                 "other_kernel": {"fwd_ms": fwd_ms, "bwd_ms": bwd_ms,
