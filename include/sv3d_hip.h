@@ -140,6 +140,46 @@ int sv3d_face_gather(const float *values, const int32_t *faces, int32_t B, int32
 int sv3d_face_scatter(const float *grad_out, const int32_t *faces, int32_t B, int32_t V, int32_t F,
                       int32_t faces_batch, const float *scale, float *grad_values, void *stream);
 
+/* The renderer call's input stage, nnutils/softras.py:58-61: the weak-perspective camera
+ * `orthographic_proj_withz` (nnutils/geom_utils.py:63-80, quat_rotate :143-161) followed by
+ * a per-axis scale and shift (the y flip of softras.py:60; the look_at transform of
+ * softras.py:33-37, which for an eye on the -z axis is a z shift):
+ *   P   = cam_scale * (q (0,X) q*) + (tx, ty, offset_z)      q is used as given, un-normalised
+ *   out = scale * P + shift                                                              */
+typedef struct sv3d_mesh_input {
+    const float *vertices;   /* [B,V,3] object space                                      */
+    const float *cams;       /* [B,7] cam_scale, tx, ty, qw, qx, qy, qz                   */
+    const int32_t *faces;    /* [FB,F,3] int32                                            */
+    int32_t num_vertices;    /* V                                                         */
+    int32_t faces_batch;     /* FB: B, or 1 for a topology shared by the batch            */
+    float offset_z;
+    float scale[3];
+    float shift[3];
+} sv3d_mesh_input;
+
+/* Replaces `proj_fn(vertices, cams, offset_z)` + flip + `vertices[faces]` of
+ * nnutils/softras.py:58-61,64 (about twenty elementwise launches in the reference) by one
+ * kernel: face_vertices [B,F,3,3] = out[b, faces[fb,f,k], :] without materialising `out`.  */
+int sv3d_project_gather(const sv3d_mesh_input *mesh, int32_t B, int32_t F, float *face_vertices,
+                        void *stream);
+
+/* Backward of sv3d_project_gather (autograd of the lines cited there):
+ *   grad_vertices [B,V,3] and grad_cams [B,7], both fully overwritten.  Sums run in a fixed
+ *   order (corner slots ascending per vertex, then a fixed tree over vertices).            */
+int sv3d_project_scatter(const sv3d_mesh_input *mesh, int32_t B, int32_t F,
+                         const float *grad_face_vertices, float *grad_vertices, float *grad_cams,
+                         void *stream);
+
+/* sv3d_project_gather + sv3d_raster_forward with the camera stage folded into the
+ * rasterizer's per-face setup kernel (one launch fewer, no round trip of face_vertices):
+ * the whole of `SoftNeuralRenderer.forward`, nnutils/softras.py:57-77, for textures that are
+ * already per face.  face_vertices_out [B,F,3,3] may be NULL when the caller has no use for
+ * it; the other arguments are those of sv3d_raster_forward (p->batch, p->num_faces give B, F).
+ * Its backward is sv3d_raster_backward followed by sv3d_project_scatter.                    */
+int sv3d_render_forward(const sv3d_raster_params *p, const sv3d_mesh_input *mesh,
+                        const float *textures, float *face_vertices_out, float *rgba_out,
+                        void *face_rec, void *pixel_saved, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -25,6 +25,7 @@
 #include <math.h>
 #include <stdint.h>
 
+#include "camera.h"
 #include "sv3d_hip.h"
 
 #ifdef SV3D_TRACE
@@ -208,18 +209,11 @@ __device__ inline int texel_index(float n0, float n1, float n2, int R)
 // ------------------------------------------------------------------------------------
 // setup
 // ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kThreads) void raster_setup_kernel(
-    DevParams P, const float *__restrict__ fv, float4 *__restrict__ rec, uint2 *__restrict__ pbox)
+// Record of face `gid` from its three camera-space corners; zref = z of the image's first corner.
+__device__ inline void setup_face(const DevParams &P, int gid, float x0, float y0, float z0, float x1,
+                                  float y1, float z1, float x2, float y2, float z2, float zref,
+                                  float4 *__restrict__ rec, uint2 *__restrict__ pbox)
 {
-    const int gid = blockIdx.x * kThreads + threadIdx.x;
-    if (gid >= P.B * P.F) return;
-    const int b = gid / P.F;
-    const float *v = fv + (size_t)gid * 9;
-    const float x0 = v[0], y0 = v[1], z0 = v[2];
-    const float x1 = v[3], y1 = v[4], z1 = v[5];
-    const float x2 = v[6], y2 = v[7], z2 = v[8];
-    const float zref = fv[(size_t)b * P.F * 9 + 2];
-
     const float e0x = x1 - x0, e0y = y1 - y0;
     const float e1x = x2 - x1, e1y = y2 - y1;
     const float e2x = x0 - x2, e2y = y0 - y2;
@@ -257,6 +251,55 @@ __global__ __launch_bounds__(kThreads) void raster_setup_kernel(
                        __int_as_float(raw_det < 0.f ? 1 : 0), zref);
     r[7] = make_float4(__uint_as_float(box.x), __uint_as_float(box.y), 0.f, 0.f);
     pbox[gid] = box;
+}
+
+__global__ __launch_bounds__(kThreads) void raster_setup_kernel(
+    DevParams P, const float *__restrict__ fv, float4 *__restrict__ rec, uint2 *__restrict__ pbox)
+{
+    const int gid = blockIdx.x * kThreads + threadIdx.x;
+    if (gid >= P.B * P.F) return;
+    const int b = gid / P.F;
+    const float *v = fv + (size_t)gid * 9;
+    setup_face(P, gid, v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], v[8],
+               fv[(size_t)b * P.F * 9 + 2], rec, pbox);
+}
+
+// Setup straight from the object-space mesh: each thread projects its face's three vertices
+// through the image's camera (camera.h), optionally stores them as face_vertices, and builds
+// the record from those same values (per corner the arithmetic is project_gather_kernel's).
+struct MeshArgs {
+    const float *vertices, *cams;
+    const int32_t *faces;
+    int V, faces_batch;
+    float offset_z;
+    sv3d_dev::Affine a;
+};
+
+__global__ __launch_bounds__(kThreads) void raster_setup_mesh_kernel(
+    DevParams P, MeshArgs m, float *__restrict__ fv_out, float4 *__restrict__ rec,
+    uint2 *__restrict__ pbox)
+{
+    const int gid = blockIdx.x * kThreads + threadIdx.x;
+    if (gid >= P.B * P.F) return;
+    const int b = gid / P.F, f = gid - b * P.F;
+    const int32_t *fb = m.faces + (m.faces_batch > 1 ? (size_t)b * P.F * 3 : 0);
+    const sv3d_dev::Camera c = sv3d_dev::load_camera(m.cams + (size_t)b * 7, m.offset_z);
+    const float *vb = m.vertices + (size_t)b * m.V * 3;
+    float o[9];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int v = min(max(fb[f * 3 + k], 0), m.V - 1);
+        sv3d_dev::camera_project(c, m.a, vb[v * 3], vb[v * 3 + 1], vb[v * 3 + 2], o[3 * k], o[3 * k + 1],
+                                 o[3 * k + 2]);
+    }
+    const int v00 = min(max(fb[0], 0), m.V - 1);
+    float rx, ry, zref;
+    sv3d_dev::camera_project(c, m.a, vb[v00 * 3], vb[v00 * 3 + 1], vb[v00 * 3 + 2], rx, ry, zref);
+    if (fv_out) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) fv_out[(size_t)gid * 9 + i] = o[i];
+    }
+    setup_face(P, gid, o[0], o[1], o[2], o[3], o[4], o[5], o[6], o[7], o[8], zref, rec, pbox);
 }
 
 __device__ inline void unpack_box(uint2 b, int &col0, int &col1, int &row0, int &row1)
@@ -842,21 +885,39 @@ extern "C" int sv3d_raster_sizes(const sv3d_raster_params *p, size_t *face_rec_b
 
 namespace {
 
+// Either face_vertices (mesh == nullptr) or the object-space mesh is the geometry source; with a
+// mesh, face_vertices is an optional output.
 int raster_forward_impl(const sv3d_raster_params *p, const float *face_vertices, const float *textures,
                         float *rgba_out, void *face_rec, void *pixel_saved, void *stream,
-                        hipEvent_t ev_start, hipEvent_t ev_stop)
+                        hipEvent_t ev_start, hipEvent_t ev_stop, const sv3d_mesh_input *mesh = nullptr)
 {
     DevParams d;
     const int st = make_dev_params(p, d);
     if (st != SV3D_OK) return st;
-    if (!face_vertices || !rgba_out || !face_rec || !pixel_saved) return SV3D_ERR_INVALID_ARG;
+    if (mesh) {
+        if (!mesh->vertices || !mesh->cams || !mesh->faces || mesh->num_vertices <= 0)
+            return SV3D_ERR_INVALID_ARG;
+        if (mesh->faces_batch != 1 && mesh->faces_batch != d.B) return SV3D_ERR_INVALID_ARG;
+    } else if (!face_vertices) {
+        return SV3D_ERR_INVALID_ARG;
+    }
+    if (!rgba_out || !face_rec || !pixel_saved) return SV3D_ERR_INVALID_ARG;
     if (d.mode != SV3D_TEX_NONE && !textures) return SV3D_ERR_INVALID_ARG;
     hipStream_t s = static_cast<hipStream_t>(stream);
     float4 *rec = static_cast<float4 *>(face_rec);
     uint2 *pbox = reinterpret_cast<uint2 *>(static_cast<float *>(face_rec) + rec_floats(d));
     const int nf = d.B * d.F;
-    hipLaunchKernelGGL(raster_setup_kernel, dim3((nf + kThreads - 1) / kThreads), dim3(kThreads), 0, s,
-                       d, face_vertices, rec, pbox);
+    if (mesh) {
+        MeshArgs m;
+        m.vertices = mesh->vertices; m.cams = mesh->cams; m.faces = mesh->faces;
+        m.V = mesh->num_vertices; m.faces_batch = mesh->faces_batch; m.offset_z = mesh->offset_z;
+        m.a = {mesh->scale[0], mesh->scale[1], mesh->scale[2], mesh->shift[0], mesh->shift[1], mesh->shift[2]};
+        hipLaunchKernelGGL(raster_setup_mesh_kernel, dim3((nf + kThreads - 1) / kThreads), dim3(kThreads), 0,
+                           s, d, m, const_cast<float *>(face_vertices), rec, pbox);
+    } else {
+        hipLaunchKernelGGL(raster_setup_kernel, dim3((nf + kThreads - 1) / kThreads), dim3(kThreads), 0, s,
+                           d, face_vertices, rec, pbox);
+    }
     const int tiles = (d.S + kTile - 1) / kTile;
     dim3 grid((unsigned)tiles * tiles * d.B), block(kThreads);
     float *saved = static_cast<float *>(pixel_saved);
@@ -920,6 +981,15 @@ extern "C" int sv3d_raster_forward(const sv3d_raster_params *p, const float *fac
 {
     return raster_forward_impl(p, face_vertices, textures, rgba_out, face_rec, pixel_saved, stream,
                                nullptr, nullptr);
+}
+
+extern "C" int sv3d_render_forward(const sv3d_raster_params *p, const sv3d_mesh_input *mesh,
+                                   const float *textures, float *face_vertices_out, float *rgba_out,
+                                   void *face_rec, void *pixel_saved, void *stream)
+{
+    if (!mesh) return SV3D_ERR_INVALID_ARG;
+    return raster_forward_impl(p, face_vertices_out, textures, rgba_out, face_rec, pixel_saved, stream,
+                               nullptr, nullptr, mesh);
 }
 
 extern "C" int sv3d_raster_forward_timed(const sv3d_raster_params *p, const float *face_vertices,

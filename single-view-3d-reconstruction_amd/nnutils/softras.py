@@ -8,6 +8,7 @@ renderer underneath is the `soft_renderer` drop-in over the sv3d HIP kernels.
 import torch
 
 import soft_renderer as sr
+import sv3d
 
 from . import geom_utils
 
@@ -47,7 +48,51 @@ class SoftNeuralRenderer(torch.nn.Module):
         """softras.py:53-55: xy of the projection, no flip, no depth offset."""
         return self.proj_fn(verts, cams)[:, :, :2]
 
+    def _camera_stage(self):
+        """(scale, shift) that express the y flip and the renderer's camera transform when
+        that transform is a pure depth shift (orthographic look_at from an eye on the -z axis,
+        as configured above); None for any other transform."""
+        t = self.renderer.transform
+        eye = t.eye
+        if self.proj_fn is not geom_utils.orthographic_proj_withz or t.camera_mode != 'look_at' \
+                or t.perspective or t.viewing_scale != 1.0 or torch.is_tensor(eye):
+            return None
+        eye = [float(e) for e in eye]
+        if len(eye) != 3 or eye[0] != 0.0 or eye[1] != 0.0 or not eye[2] < 0.0:
+            return None
+        return (1.0, -1.0, 1.0), (0.0, 0.0, -eye[2])
+
     def forward(self, vertices, faces, cams, textures=None, part_seg=False):
+        stage = self._camera_stage()
+        if stage is not None:
+            return self._forward_fused(vertices, faces, cams, textures, *stage)
+        return self._forward_staged(vertices, faces, cams, textures)
+
+    def _forward_fused(self, vertices, faces, cams, textures, scale, shift):
+        """The renderer call with camera, flip, depth shift, gather and face setup inside the
+        HIP ops (one launch) instead of some twenty elementwise launches."""
+        r = self.renderer.rasterizer
+        kw = dict(offset_z=self.offset_z, scale=scale, shift=shift, anti_aliasing=r.anti_aliasing,
+                  background_color=r.background_color, near=r.near, far=r.far, eps=r.eps,
+                  sigma_val=r.sigma_val, dist_eps=r.dist_eps, gamma_val=r.gamma_val, fill_back=r.fill_back)
+        if textures is None:
+            self.mask_only = True
+            return sv3d.render(vertices, cams, faces, None, r.image_size, **kw)[:, -1]
+        self.mask_only = False
+        if self.part_seg:
+            self.renderer.set_texture_mode('vertex')
+            colours = sv3d.face_gather(textures, faces if faces.dtype == torch.int32 else faces.to(torch.int32))
+            return sv3d.render(vertices, cams, faces, colours, r.image_size, texture_type='vertex', **kw)[:, :3]
+        self.renderer.set_texture_mode('surface')
+        lighting = self.renderer.lighting
+        if lighting.is_identity():
+            return sv3d.render(vertices, cams, faces, textures, r.image_size, **kw)[:, :3]
+        fv = sv3d.project_gather(vertices, cams, faces, self.offset_z, scale, shift)
+        lit = textures * lighting.surface_light(fv)[:, :, None, :]
+        kw.pop('offset_z'), kw.pop('scale'), kw.pop('shift')
+        return sv3d.soft_rasterize(fv, lit, r.image_size, **kw)[:, :3]
+
+    def _forward_staged(self, vertices, faces, cams, textures):
         verts = self.proj_fn(vertices, cams, offset_z=self.offset_z)
         vs = verts * verts.new_tensor([1.0, -1.0, 1.0])               # image y points down
         if textures is None:

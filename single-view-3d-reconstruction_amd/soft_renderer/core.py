@@ -29,6 +29,13 @@ def _as_batched(x, dtype, device=None):
     return x.to(dtype) if x.dtype != dtype else x
 
 
+def face_normals(fv):
+    """Unit normals [B,F,3] of face_vertices [B,F,3,3]."""
+    v10 = fv[:, :, 0] - fv[:, :, 1]
+    v12 = fv[:, :, 2] - fv[:, :, 1]
+    return F.normalize(torch.cross(v12, v10, dim=-1), p=2, dim=2, eps=1e-6)
+
+
 class Mesh(object):
     """Batched triangle mesh: vertices [B,V,3], faces [B,F,3], textures [B,F,R*R,3]
     ('surface') or [B,V,3] ('vertex')."""
@@ -83,13 +90,19 @@ class Mesh(object):
 
     @property
     def surface_normals(self):
-        fv = self.face_vertices
-        v10 = fv[:, :, 0] - fv[:, :, 1]
-        v12 = fv[:, :, 2] - fv[:, :, 1]
-        return F.normalize(torch.cross(v12, v10, dim=-1), p=2, dim=2, eps=1e-6)
+        return face_normals(self.face_vertices)
 
 
 # ---- lighting -----------------------------------------------------------------------
+def _rgb_scaled(x, color, k):
+    """x[..., None] * k * color as [..., 3], from Python scalars only: no host-to-device copy, so
+    the lighting can be captured in a HIP graph.  A tensor colour is used as it is."""
+    if torch.is_tensor(color):
+        return x[..., None] * (k * color.to(x.device, x.dtype))
+    c = [float(v) * float(k) for v in np.asarray(color, dtype=np.float64).reshape(-1)]
+    return torch.stack((x * c[0], x * c[1], x * c[2]), dim=-1)
+
+
 class AmbientLighting(nn.Module):
     def __init__(self, light_intensity=0.5, light_color=(1, 1, 1)):
         super(AmbientLighting, self).__init__()
@@ -97,8 +110,12 @@ class AmbientLighting(nn.Module):
         self.light_color = light_color
 
     def forward(self, light):
-        c = torch.as_tensor(self.light_color, dtype=light.dtype, device=light.device)
-        return light + self.light_intensity * c
+        if torch.is_tensor(self.light_color):
+            return light + self.light_intensity * self.light_color.to(light.device, light.dtype)
+        c = [float(v) * float(self.light_intensity) for v in np.asarray(self.light_color, dtype=np.float64).reshape(-1)]
+        if c[0] == c[1] == c[2]:
+            return light + c[0]
+        return torch.stack((light[..., 0] + c[0], light[..., 1] + c[1], light[..., 2] + c[2]), dim=-1)
 
 
 class DirectionalLighting(nn.Module):
@@ -109,10 +126,13 @@ class DirectionalLighting(nn.Module):
         self.light_direction = light_direction
 
     def forward(self, light, normals):
-        c = torch.as_tensor(self.light_color, dtype=light.dtype, device=light.device)
-        d = torch.as_tensor(self.light_direction, dtype=light.dtype, device=light.device)
-        cosine = F.relu((normals * d).sum(-1))
-        return light + self.light_intensity * c * cosine[..., None]
+        if torch.is_tensor(self.light_direction):
+            d = self.light_direction.to(normals.device, normals.dtype)
+            cosine = F.relu((normals * d).sum(-1))
+        else:
+            d = [float(v) for v in np.asarray(self.light_direction, dtype=np.float64).reshape(-1)]
+            cosine = F.relu(normals[..., 0] * d[0] + normals[..., 1] * d[1] + normals[..., 2] * d[2])
+        return light + _rgb_scaled(cosine, self.light_color, self.light_intensity)
 
 
 class Lighting(nn.Module):
@@ -133,16 +153,23 @@ class Lighting(nn.Module):
         amb = np.asarray(self.ambient.light_color, dtype=np.float64) * self.ambient.light_intensity
         return bool(np.all(amb == 1.0)) and all(float(d.light_intensity) == 0.0 for d in self.directionals)
 
+    def surface_light(self, face_vertices):
+        """Per-face light colour [B,F,3] for face_vertices [B,F,3,3] (normals do not depend on
+        a translation of the mesh, so camera-space corners serve as well)."""
+        B, nf = face_vertices.shape[0], face_vertices.shape[1]
+        light = torch.zeros(B, nf, 3, dtype=torch.float32, device=face_vertices.device)
+        light = self.ambient(light)
+        if any(float(d.light_intensity) != 0.0 for d in self.directionals):
+            normals = face_normals(face_vertices)
+            for directional in self.directionals:
+                light = directional(light, normals)
+        return light
+
     def forward(self, mesh):
         if self.is_identity():
             return mesh                             # textures * 1: skip a full pass over the texels
         if self.light_mode == 'surface':
-            light = torch.zeros(mesh.batch_size, mesh.num_faces, 3, dtype=torch.float32, device=mesh.device)
-            light = self.ambient(light)
-            if any(float(d.light_intensity) != 0.0 for d in self.directionals):
-                normals = mesh.surface_normals
-                for directional in self.directionals:
-                    light = directional(light, normals)
+            light = self.surface_light(mesh.face_vertices)
             mesh.textures = mesh.textures * light[:, :, None, :]
         else:
             if any(float(d.light_intensity) != 0.0 for d in self.directionals):

@@ -17,6 +17,7 @@ EXPORTS = (
     "sv3d_raster_backward", "sv3d_raster_forward_timed", "sv3d_raster_backward_timed",
     "sv3d_chamfer_forward", "sv3d_chamfer_backward",
     "sv3d_face_gather", "sv3d_face_scatter",
+    "sv3d_project_gather", "sv3d_project_scatter", "sv3d_render_forward",
 )
 
 
@@ -30,6 +31,15 @@ class RasterParams(ctypes.Structure):
         ("background", ctypes.c_float * 3),
         ("near_plane", ctypes.c_float), ("far_plane", ctypes.c_float), ("eps", ctypes.c_float),
         ("sigma", ctypes.c_float), ("dist_eps", ctypes.c_float), ("gamma", ctypes.c_float),
+    ]
+
+
+class MeshInput(ctypes.Structure):
+    """Mirror of `sv3d_mesh_input`."""
+    _fields_ = [
+        ("vertices", ctypes.c_void_p), ("cams", ctypes.c_void_p), ("faces", ctypes.c_void_p),
+        ("num_vertices", ctypes.c_int32), ("faces_batch", ctypes.c_int32),
+        ("offset_z", ctypes.c_float), ("scale", ctypes.c_float * 3), ("shift", ctypes.c_float * 3),
     ]
 
 
@@ -66,6 +76,10 @@ def lib():
         f3 = ctypes.POINTER(ctypes.c_float)
         L.sv3d_face_gather.argtypes = [vp, vp, i32, i32, i32, i32, f3, f3, vp, vp]
         L.sv3d_face_scatter.argtypes = [vp, vp, i32, i32, i32, i32, f3, vp, vp]
+        mp = ctypes.POINTER(MeshInput)
+        L.sv3d_project_gather.argtypes = [mp, i32, i32, vp, vp]
+        L.sv3d_project_scatter.argtypes = [mp, i32, i32, vp, vp, vp, vp]
+        L.sv3d_render_forward.argtypes = [pp, mp, vp, vp, vp, vp, vp, vp]
         for name in EXPORTS:
             if name != "sv3d_strerror":
                 getattr(L, name).restype = ctypes.c_int
@@ -95,6 +109,18 @@ def raster_sizes(p):
     check(lib().sv3d_raster_sizes(ctypes.byref(p), ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)),
           "sv3d_raster_sizes")
     return a.value, b.value, c.value
+
+
+def make_mesh_input(vertices, cams, faces, offset_z, scale, shift):
+    """`sv3d_mesh_input` over three CUDA(HIP) tensors (kept alive by the caller for the call)."""
+    m = MeshInput()
+    m.vertices, m.cams, m.faces = vertices.data_ptr(), cams.data_ptr(), faces.data_ptr()
+    m.num_vertices, m.faces_batch = int(vertices.shape[1]), int(faces.shape[0])
+    m.offset_z = float(offset_z)
+    for i in range(3):
+        m.scale[i] = float(scale[i])
+        m.shift[i] = float(shift[i])
+    return m
 
 
 def float3(values):

@@ -7,6 +7,9 @@ Ops (namespace `sv3d`), all CUDA(HIP)-only -- a CPU tensor raises, there is no f
   chamfer_nn / chamfer_nn_backward           the third-party ChamferDistance called at
                                              nnutils/loss_utils.py:85-86
   face_gather / face_scatter                 sr.Mesh's `vertices[faces]` + affine pre-stage
+  project_gather / project_scatter           camera + flip + gather of nnutils/softras.py:58-61
+  render / render_backward                   the whole renderer call of softras.py:57-77 from
+                                             the object-space mesh (camera folded into setup)
 
 torch is used for device memory, streams and autograd plumbing only.
 """
@@ -318,3 +321,212 @@ def face_gather(values, faces, scale=(1.0, 1.0, 1.0), shift=(0.0, 0.0, 0.0)):
         faces = faces.to(torch.int32)
     return face_gather_op(values, faces.contiguous(), [float(s) for s in scale],
                           [float(s) for s in shift])
+
+
+# ---- camera + gather, and the renderer call from the object-space mesh -----------------
+def _check_mesh(vertices, cams, faces):
+    if vertices.dim() != 3 or vertices.shape[2] != 3:
+        raise ValueError("vertices must be [B,V,3], got %s" % (tuple(vertices.shape),))
+    if cams.dim() != 2 or tuple(cams.shape) != (vertices.shape[0], 7):
+        raise ValueError("cams must be [B,7], got %s" % (tuple(cams.shape),))
+    if faces.dim() != 3 or faces.shape[2] != 3 or faces.dtype != torch.int32 \
+            or faces.shape[0] not in (1, vertices.shape[0]):
+        raise ValueError("faces must be int32 [B or 1,F,3], got %s %s" % (faces.dtype, tuple(faces.shape)))
+
+
+@torch.library.custom_op("sv3d::project_gather", mutates_args=(), device_types="cuda")
+def project_gather_op(vertices: Tensor, cams: Tensor, faces: Tensor, offset_z: float,
+                      scale: List[float], shift: List[float]) -> Tensor:
+    _check_mesh(vertices, cams, faces)
+    v, c, f = _f32c(vertices), _f32c(cams), faces.contiguous()
+    B, F = v.shape[0], f.shape[1]
+    with torch.cuda.device(v.device):
+        out = torch.empty((B, F, 3, 3), dtype=torch.float32, device=v.device)
+        m = L.make_mesh_input(v, c, f, offset_z, scale, shift)
+        L.check(L.lib().sv3d_project_gather(ctypes.byref(m), B, F, _ptr(out), _stream(v)),
+                "sv3d_project_gather")
+    return out
+
+
+@project_gather_op.register_fake
+def _(vertices, cams, faces, offset_z, scale, shift):
+    return vertices.new_empty((vertices.shape[0], faces.shape[1], 3, 3), dtype=torch.float32)
+
+
+@torch.library.custom_op("sv3d::project_scatter", mutates_args=(), device_types="cuda")
+def project_scatter_op(grad_out: Tensor, vertices: Tensor, cams: Tensor, faces: Tensor,
+                       offset_z: float, scale: List[float]) -> Tuple[Tensor, Tensor]:
+    g, v, c = _f32c(grad_out), _f32c(vertices), _f32c(cams)
+    B, F = g.shape[0], g.shape[1]
+    with torch.cuda.device(g.device):
+        gv = torch.empty_like(v)
+        gc = torch.empty_like(c)
+        m = L.make_mesh_input(v, c, faces, offset_z, scale, (0.0, 0.0, 0.0))
+        L.check(L.lib().sv3d_project_scatter(ctypes.byref(m), B, F, _ptr(g), _ptr(gv), _ptr(gc),
+                                             _stream(g)), "sv3d_project_scatter")
+    return gv, gc
+
+
+@project_scatter_op.register_fake
+def _(grad_out, vertices, cams, faces, offset_z, scale):
+    return (torch.empty_like(vertices, dtype=torch.float32), torch.empty_like(cams, dtype=torch.float32))
+
+
+def _project_setup_context(ctx, inputs, output):
+    vertices, cams, faces, offset_z, scale, _ = inputs
+    ctx.save_for_backward(vertices, cams, faces)
+    ctx.offset_z, ctx.scale = offset_z, list(scale)
+
+
+def _project_backward(ctx, grad_out):
+    vertices, cams, faces = ctx.saved_tensors
+    gv, gc = project_scatter_op(grad_out, vertices, cams, faces, ctx.offset_z, ctx.scale)
+    return gv.to(vertices.dtype), gc.to(cams.dtype), None, None, None, None
+
+
+project_gather_op.register_autograd(_project_backward, setup_context=_project_setup_context)
+
+
+def _faces_i32(faces):
+    if faces.dtype != torch.int32:
+        faces = faces.to(torch.int32)
+    return faces.contiguous()
+
+
+def project_gather(vertices, cams, faces, offset_z=0.0, scale=(1.0, 1.0, 1.0), shift=(0.0, 0.0, 0.0)):
+    """face_vertices [B,F,3,3] of the mesh seen through the weak-perspective cameras `cams`
+    [B,7] = (s, tx, ty, quaternion): out = scale * (s * rot(q, X) + (tx, ty, offset_z)) + shift
+    gathered per face corner (nnutils/softras.py:58-61 + `vertices[faces]`); differentiable
+    with respect to vertices and cams."""
+    return project_gather_op(vertices, cams, _faces_i32(faces), float(offset_z),
+                             [float(s) for s in scale], [float(s) for s in shift])
+
+
+@torch.library.custom_op("sv3d::render", mutates_args=(), device_types="cuda")
+def render_op(vertices: Tensor, cams: Tensor, faces: Tensor, textures: Optional[Tensor],
+              offset_z: float, scale: List[float], shift: List[float], raster_size: int, aa: int,
+              texture_mode: int, texture_res: int, double_side: bool, background: List[float],
+              near: float, far: float, eps: float, sigma: float, dist_eps: float,
+              gamma: float) -> Tuple[Tensor, Tensor, Tensor]:
+    _check_mesh(vertices, cams, faces)
+    v, c, f = _f32c(vertices), _f32c(cams), faces.contiguous()
+    B, F = v.shape[0], f.shape[1]
+    if texture_mode != L.SV3D_TEX_NONE:
+        want = (B, F, texture_res * texture_res, 3) if texture_mode == L.SV3D_TEX_SURFACE else (B, F, 3, 3)
+        if textures is None or tuple(textures.shape) != want:
+            raise ValueError("textures must be %s" % (want,))
+    tex = _f32c(textures) if texture_mode != L.SV3D_TEX_NONE else None
+    p = L.make_params(B, F, raster_size, aa, texture_mode, texture_res, double_side, background,
+                      near, far, eps, sigma, dist_eps, gamma)
+    rec_b, saved_b, _ = L.raster_sizes(p)
+    H = raster_size // aa
+    with torch.cuda.device(v.device):
+        rgba = torch.empty((B, 4, H, H), dtype=torch.float32, device=v.device)
+        rec = torch.empty(rec_b // 4, dtype=torch.float32, device=v.device)
+        saved = torch.empty(saved_b // 4, dtype=torch.float32, device=v.device)
+        m = L.make_mesh_input(v, c, f, offset_z, scale, shift)
+        L.check(L.lib().sv3d_render_forward(ctypes.byref(p), ctypes.byref(m), _ptr(tex), None, _ptr(rgba),
+                                            _ptr(rec), _ptr(saved), _stream(v)), "sv3d_render_forward")
+    return rgba, rec, saved
+
+
+@render_op.register_fake
+def _(vertices, cams, faces, textures, offset_z, scale, shift, raster_size, aa, texture_mode, texture_res,
+      double_side, background, near, far, eps, sigma, dist_eps, gamma):
+    B, F = vertices.shape[0], faces.shape[1]
+    H = raster_size // aa
+    per = 1 if texture_mode == L.SV3D_TEX_NONE else 6
+    return (vertices.new_empty((B, 4, H, H), dtype=torch.float32),
+            vertices.new_empty((B * F * 34,), dtype=torch.float32),
+            vertices.new_empty((B * raster_size * raster_size * per,), dtype=torch.float32))
+
+
+@torch.library.custom_op("sv3d::render_backward", mutates_args=(), device_types="cuda")
+def render_backward_op(grad_rgba: Tensor, vertices: Tensor, cams: Tensor, faces: Tensor,
+                       textures: Optional[Tensor], face_rec: Tensor, pixel_saved: Tensor,
+                       offset_z: float, scale: List[float], raster_size: int, aa: int,
+                       texture_mode: int, texture_res: int, double_side: bool,
+                       background: List[float], near: float, far: float, eps: float, sigma: float,
+                       dist_eps: float, gamma: float,
+                       need_textures: bool) -> Tuple[Tensor, Tensor, Tensor]:
+    g, v, c = _f32c(grad_rgba), _f32c(vertices), _f32c(cams)
+    tex = _f32c(textures) if texture_mode != L.SV3D_TEX_NONE else None
+    B, F = v.shape[0], faces.shape[1]
+    p = L.make_params(B, F, raster_size, aa, texture_mode, texture_res, double_side, background,
+                      near, far, eps, sigma, dist_eps, gamma)
+    _, _, ws_b = L.raster_sizes(p)
+    with torch.cuda.device(g.device):
+        gfv = torch.empty((B, F, 3, 3), dtype=torch.float32, device=g.device)
+        gtex = torch.empty_like(tex) if (tex is not None and need_textures) else \
+            torch.empty(0, dtype=torch.float32, device=g.device)
+        ws = torch.empty(ws_b // 4, dtype=torch.float32, device=g.device)
+        gv, gc = torch.empty_like(v), torch.empty_like(c)
+        st = _stream(g)
+        L.check(L.lib().sv3d_raster_backward(ctypes.byref(p), _ptr(tex), _ptr(face_rec), _ptr(pixel_saved),
+                                             _ptr(g), _ptr(gfv), _ptr(gtex), _ptr(ws), ctypes.c_size_t(ws_b),
+                                             st), "sv3d_raster_backward")
+        m = L.make_mesh_input(v, c, faces, offset_z, scale, (0.0, 0.0, 0.0))
+        L.check(L.lib().sv3d_project_scatter(ctypes.byref(m), B, F, _ptr(gfv), _ptr(gv), _ptr(gc), st),
+                "sv3d_project_scatter")
+    return gv, gc, gtex
+
+
+@render_backward_op.register_fake
+def _(grad_rgba, vertices, cams, faces, textures, face_rec, pixel_saved, offset_z, scale, raster_size, aa,
+      texture_mode, texture_res, double_side, background, near, far, eps, sigma, dist_eps, gamma,
+      need_textures):
+    gtex = torch.empty_like(textures, dtype=torch.float32) if (textures is not None and need_textures) \
+        else grad_rgba.new_empty((0,), dtype=torch.float32)
+    return (torch.empty_like(vertices, dtype=torch.float32), torch.empty_like(cams, dtype=torch.float32), gtex)
+
+
+def _render_setup_context(ctx, inputs, output):
+    vertices, cams, faces, tex = inputs[0], inputs[1], inputs[2], inputs[3]
+    _, rec, saved = output
+    ctx.offset_z, ctx.scale = inputs[4], list(inputs[5])
+    ctx.scalars = tuple(inputs[7:])
+    ctx.has_tex = tex is not None and inputs[9] != L.SV3D_TEX_NONE
+    if ctx.has_tex:
+        ctx.save_for_backward(vertices, cams, faces, rec, saved, tex)
+    else:
+        ctx.save_for_backward(vertices, cams, faces, rec, saved)
+
+
+def _render_backward(ctx, grad_rgba, grad_rec, grad_saved):
+    vertices, cams, faces, rec, saved = ctx.saved_tensors[:5]
+    tex = ctx.saved_tensors[5] if ctx.has_tex else None
+    need_tex = ctx.has_tex and ctx.needs_input_grad[3]
+    gv, gc, gtex = render_backward_op(grad_rgba, vertices, cams, faces, tex, rec, saved, ctx.offset_z,
+                                      ctx.scale, *ctx.scalars, need_tex)
+    return (gv.to(vertices.dtype), gc.to(cams.dtype), None, gtex.to(tex.dtype) if need_tex else None) + \
+        (None,) * 15
+
+
+render_op.register_autograd(_render_backward, setup_context=_render_setup_context)
+
+
+def render(vertices, cams, faces, textures=None, image_size=256, *, offset_z=0.0,
+           scale=(1.0, 1.0, 1.0), shift=(0.0, 0.0, 0.0), anti_aliasing=False, texture_type="surface",
+           background_color=(0.0, 0.0, 0.0), near=1.0, far=100.0, eps=1e-3, sigma_val=1e-5,
+           dist_eps=1e-10, gamma_val=1e-4, fill_back=True):
+    """`project_gather` + `soft_rasterize` as one op: RGBA [B,4,image_size,image_size] of the mesh
+    (vertices [B,V,3] object space, faces [B or 1,F,3]) seen through `cams` [B,7].  `textures` are
+    per face as for `soft_rasterize` ([B,F,R*R,3] or per-corner [B,F,3,3]).  Differentiable with
+    respect to vertices, cams and textures."""
+    aa = 2 if anti_aliasing else 1
+    if textures is None:
+        mode, res = L.SV3D_TEX_NONE, 1
+    elif texture_type == "surface":
+        mode = L.SV3D_TEX_SURFACE
+        res = int(round(textures.shape[2] ** 0.5))
+        if res * res != textures.shape[2]:
+            raise ValueError("surface textures need a square texel count, got %d" % textures.shape[2])
+    elif texture_type == "vertex":
+        mode, res = L.SV3D_TEX_VERTEX, 1
+    else:
+        raise ValueError("unknown texture_type %r" % (texture_type,))
+    rgba, _, _ = render_op(vertices, cams, _faces_i32(faces), textures, float(offset_z),
+                           [float(s) for s in scale], [float(s) for s in shift], int(image_size) * aa, aa,
+                           mode, res, bool(fill_back), [float(c) for c in background_color], float(near),
+                           float(far), float(eps), float(sigma_val), float(dist_eps), float(gamma_val))
+    return rgba
