@@ -5,7 +5,8 @@ renderer / Chamfer call pattern of one training iteration:
 
   images + mirrored images (2B) -> encoder -> shape deltas, Nc = 8 camera hypotheses, texture flow
   vs/fs/ts replicated Nc times (main.py:413-415)  ->  Bn = Nc * 2B rendered images per call
-  1 mask render + 1 texture render + Np vertex-colour part renders       (main.py:417-426)
+  1 mask render + 1 texture render + Np vertex-colour part renders       (main.py:417-426),
+  or the same images from 1 + ceil(Np/3) rasterizer passes (--share_renders 1, the default)
   per-hypothesis mask / texture losses -> softmin camera weights          (main.py:435-445)
   chamfer(pred_v.detach(), mirrored pred_v of the flipped half)           (main.py:522-525)
   Laplacian + flatten regularisers                                       (main.py:515-516)
@@ -160,8 +161,11 @@ class ShapeTrainer(train_utils.Trainer):
         fs = torch.cat([faces] * Nc)
         ts = torch.cat([textures] * Nc)
         proj_cam = cams.permute(1, 0, 2).reshape(Nc * B2, 7)
-        mask_pred = self.renderer(vs, fs, proj_cam)                         # Nc*2B x H x W
-        tex_pred = self.tex_renderer(vs, fs, proj_cam, textures=ts)
+        if o.share_renders:
+            tex_pred, mask_pred = self.tex_renderer.forward_with_mask(vs, fs, proj_cam, ts)
+        else:
+            mask_pred = self.renderer(vs, fs, proj_cam)                     # Nc*2B x H x W
+            tex_pred = self.tex_renderer(vs, fs, proj_cam, textures=ts)
         mask_loss = ((mask_pred - torch.cat([masks_gt] * Nc)) ** 2).flatten(1).mean(1)
         tex_loss = ((tex_pred - torch.cat([all_imgs] * Nc)).abs() * torch.cat([masks_gt] * Nc)[:, None]).flatten(1).mean(1)
         per_cam = (mask_loss + tex_loss).view(Nc, B2)
@@ -171,9 +175,13 @@ class ShapeTrainer(train_utils.Trainer):
         if o.seg_train and Np > 0:
             w = train_utils.unwrap(self.part_basis_generator).weight        # V x Np
             seg_map = F.softmax(w, dim=1)[None].expand(B2, -1, -1)
-            seg = [self.vertex_seg_renderer(vs, fs, proj_cam, torch.cat([seg_map[:, :, k:k + 1].repeat(1, 1, 3)] * Nc),
-                                            True)[:, 0:1] for k in range(Np)]       # main.py:422-426
-            seg = torch.cat(seg, 1)
+            if o.share_renders:
+                seg = self.vertex_seg_renderer.render_parts(vs, fs, proj_cam, torch.cat([seg_map] * Nc))
+            else:
+                seg = [self.vertex_seg_renderer(vs, fs, proj_cam,
+                                                torch.cat([seg_map[:, :, k:k + 1].repeat(1, 1, 3)] * Nc),
+                                                True)[:, 0:1] for k in range(Np)]   # main.py:422-426
+                seg = torch.cat(seg, 1)
             loss = loss + 0.1 * ((seg.sum(1) - mask_pred.detach()) ** 2).mean()
         Bh = B2 // 2
         mirror = pred_v.new_tensor([-1.0, 1.0, 1.0])
@@ -191,6 +199,9 @@ def parse(argv=None):
     p.add_argument('--num_parts', type=int, default=8)
     p.add_argument('--chamf_loss_wt', type=float, default=1.0)
     p.add_argument('--dataset_size', type=int, default=512)
+    p.add_argument('--share_renders', type=int, default=1,
+                   help='1: silhouette from the RGB pass and three part maps per pass; 0: the '
+                        "reference's 2 + Np separate renders")
     o = p.parse_args(argv)
     return o
 
@@ -211,7 +222,8 @@ def main(argv=None):
     dt = time.time() - t0
     if t.env.is_main:
         Bn = o.num_hypo_cams * 2 * o.batch_size
-        renders = 2 + (o.num_parts if o.seg_train else 0)
+        parts = o.num_parts if o.seg_train else 0
+        renders = 1 + (parts + 2) // 3 if o.share_renders else 2 + parts
         print('steps %d, %.1f ms/step, %.1f dataset images/s over %d rank(s) (%d rendered images x %d renders per step per rank)'
               % (steps, 1e3 * dt / max(steps, 1), steps * o.batch_size * t.env.world_size / dt, t.env.world_size, Bn, renders))
     return t

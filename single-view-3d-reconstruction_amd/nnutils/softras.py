@@ -71,26 +71,61 @@ class SoftNeuralRenderer(torch.nn.Module):
     def _forward_fused(self, vertices, faces, cams, textures, scale, shift):
         """The renderer call with camera, flip, depth shift, gather and face setup inside the
         HIP ops (one launch) instead of some twenty elementwise launches."""
+        rgba = self._rgba_fused(vertices, faces, cams, textures, scale, shift)
+        return rgba[:, -1] if textures is None else rgba[:, :3]
+
+    def _rgba_fused(self, vertices, faces, cams, textures, scale, shift):
         r = self.renderer.rasterizer
         kw = dict(offset_z=self.offset_z, scale=scale, shift=shift, anti_aliasing=r.anti_aliasing,
                   background_color=r.background_color, near=r.near, far=r.far, eps=r.eps,
                   sigma_val=r.sigma_val, dist_eps=r.dist_eps, gamma_val=r.gamma_val, fill_back=r.fill_back)
         if textures is None:
             self.mask_only = True
-            return sv3d.render(vertices, cams, faces, None, r.image_size, **kw)[:, -1]
+            return sv3d.render(vertices, cams, faces, None, r.image_size, **kw)
         self.mask_only = False
         if self.part_seg:
             self.renderer.set_texture_mode('vertex')
             colours = sv3d.face_gather(textures, faces if faces.dtype == torch.int32 else faces.to(torch.int32))
-            return sv3d.render(vertices, cams, faces, colours, r.image_size, texture_type='vertex', **kw)[:, :3]
+            return sv3d.render(vertices, cams, faces, colours, r.image_size, texture_type='vertex', **kw)
         self.renderer.set_texture_mode('surface')
         lighting = self.renderer.lighting
         if lighting.is_identity():
-            return sv3d.render(vertices, cams, faces, textures, r.image_size, **kw)[:, :3]
+            return sv3d.render(vertices, cams, faces, textures, r.image_size, **kw)
         fv = sv3d.project_gather(vertices, cams, faces, self.offset_z, scale, shift)
         lit = textures * lighting.surface_light(fv)[:, :, None, :]
         kw.pop('offset_z'), kw.pop('scale'), kw.pop('shift')
-        return sv3d.soft_rasterize(fv, lit, r.image_size, **kw)[:, :3]
+        return sv3d.soft_rasterize(fv, lit, r.image_size, **kw)
+
+    # ---- renders that share one rasterizer pass ------------------------------------------
+    # The reference's training step renders the same (vertices, faces, cams) ten times per
+    # iteration (main.py:417-426): a silhouette, an RGB image, and Np part maps one at a time,
+    # each part map copied into three identical colour channels of which one is kept.  The
+    # silhouette is the alpha channel every colour pass computes anyway, and the three colour
+    # channels of a vertex-colour pass are independent, so the same images come out of
+    # 1 + ceil(Np / 3) passes.
+    def forward_with_mask(self, vertices, faces, cams, textures):
+        """(forward(vertices, faces, cams, textures), forward(vertices, faces, cams)) from one
+        pass: RGB [B,3,H,W] and the silhouette [B,H,W]."""
+        stage = self._camera_stage()
+        if stage is None:
+            return self.forward(vertices, faces, cams, textures), self.forward(vertices, faces, cams)
+        rgba = self._rgba_fused(vertices, faces, cams, textures, *stage)
+        return rgba[:, :3], rgba[:, 3]
+
+    def render_parts(self, vertices, faces, cams, part_maps):
+        """part_maps [B,V,Np] -> [B,Np,H,W], equal to stacking
+        forward(vertices, faces, cams, part_maps[:, :, k:k+1].repeat(1, 1, 3))[:, 0:1] over k
+        (main.py:422-426), three maps per rasterizer pass.  Needs texture_type='vertex'."""
+        if not self.part_seg:
+            raise ValueError("render_parts needs a renderer built with texture_type='vertex'")
+        n = part_maps.shape[2]
+        out = []
+        for k in range(0, n, 3):
+            group = part_maps[:, :, k:k + 3]
+            if group.shape[2] < 3:
+                group = torch.nn.functional.pad(group, (0, 3 - group.shape[2]))
+            out.append(self.forward(vertices, faces, cams, group)[:, :min(3, n - k)])
+        return torch.cat(out, dim=1)
 
     def _forward_staged(self, vertices, faces, cams, textures):
         verts = self.proj_fn(vertices, cams, offset_z=self.offset_z)

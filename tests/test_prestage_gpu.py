@@ -185,3 +185,44 @@ def test_render_forward_writes_face_vertices_and_validates():
     assert L.lib().sv3d_render_forward(ctypes.byref(p), ctypes.byref(m), None, vp(fv), vp(rgba), vp(rec),
                                        vp(saved), st) == -1
     assert L.lib().sv3d_project_gather(ctypes.byref(m), B, F, vp(fv), st) == -1
+
+
+def test_shared_pass_renders_equal_the_separate_calls():
+    """forward_with_mask / render_parts against the 2 + Np separate calls of main.py:417-426."""
+    from nnutils.softras import SoftNeuralRenderer
+    B, img, Np = 2, 32, 5
+    verts, faces = load_mesh(2)
+    v, cams = random_vertices(verts, B, 0).cuda(), random_cams(B, 1).cuda()
+    f = faces.long()[None].repeat(B, 1, 1).cuda()
+    gen = torch.Generator().manual_seed(3)
+    tex = torch.rand(B, f.shape[1], 16, 3, generator=gen).cuda()
+    parts = torch.softmax(torch.randn(B, v.shape[1], Np, generator=gen), dim=2).cuda()
+    mask_r, tex_r = SoftNeuralRenderer(img), SoftNeuralRenderer(img)
+    tex_r.ambient_light_only()
+    seg_r = SoftNeuralRenderer(img, texture_type='vertex')
+
+    def run(shared):
+        vg, cg = v.clone().requires_grad_(True), cams.clone().requires_grad_(True)
+        tg, pg = tex.clone().requires_grad_(True), parts.clone().requires_grad_(True)
+        if shared:
+            rgb, mask = tex_r.forward_with_mask(vg, f, cg, tg)
+            seg = seg_r.render_parts(vg, f, cg, pg)
+        else:
+            mask = mask_r(vg, f, cg)
+            rgb = tex_r(vg, f, cg, textures=tg)
+            seg = torch.cat([seg_r(vg, f, cg, pg[:, :, k:k + 1].repeat(1, 1, 3), True)[:, 0:1] for k in range(Np)], 1)
+        wg = torch.Generator().manual_seed(11)
+        loss = (mask * torch.rand(mask.shape, generator=wg).cuda()).sum() \
+            + (rgb * torch.rand(rgb.shape, generator=wg).cuda()).sum() \
+            + (seg * torch.rand(seg.shape, generator=wg).cuda()).sum()
+        loss.backward()
+        return [t.detach().cpu() for t in (mask, rgb, seg, vg.grad, cg.grad, tg.grad, pg.grad)]
+
+    a, b = run(True), run(False)
+    assert a[2].shape == (B, Np, img, img)
+    for x, y in zip(a[:3], b[:3]):
+        assert rel_err(x, y) < 1e-6                 # same images
+    for x, y in zip(a[3:], b[3:]):
+        assert rel_err(x, y) < 1e-5                 # same gradients, summed in a different order
+    with pytest.raises(ValueError):
+        tex_r.render_parts(v, f, cams, parts)
