@@ -153,7 +153,7 @@ __device__ inline PairGeom pair_geom(const FaceRec &r, float xp, float yp, const
     g.k0 = (dd0 <= dd1) && (dd0 <= dd2);
     g.k1 = !g.k0 && (dd1 <= dd2);
     g.k2 = !g.k0 && !g.k1;
-    g.d2 = g.k0 ? dd0 : (g.k1 ? dd1 : dd2);
+    g.d2 = fminf(dd0, fminf(dd1, dd2));            // what the selection below picks; one v_min3
     g.t = g.k0 ? t0 : (g.k1 ? t1 : t2);
     g.dx = g.k0 ? d0x : (g.k1 ? d1x : d2x);
     g.dy = g.k0 ? d0y : (g.k1 ? d1y : d2y);
