@@ -63,8 +63,9 @@ int sv3d_abi_version(void);
 /* Byte sizes of the buffers the rasterizer calls need:
  *   face_rec_bytes    per-face setup records written by forward, read by backward
  *   pixel_saved_bytes per-raster-pixel aggregates written by forward, read by backward
- *   backward_ws_bytes scratch for backward (contents undefined before and after); 0 in
- *                     silhouette mode, where `workspace` may be NULL                    */
+ *   backward_ws_bytes scratch for backward; always 0 (the backward folds its inputs on
+ *                     the fly), kept so that callers sized by this query stay valid;
+ *                     `workspace` may be NULL                                           */
 int sv3d_raster_sizes(const sv3d_raster_params *p, size_t *face_rec_bytes,
                       size_t *pixel_saved_bytes, size_t *backward_ws_bytes);
 

@@ -575,40 +575,6 @@ __global__ __launch_bounds__(kThreads) void raster_forward_kernel(
 // ------------------------------------------------------------------------------------
 // backward
 // ------------------------------------------------------------------------------------
-// Per raster pixel, fold the incoming gradient with the saved aggregates:
-//   NONE    : { g_alpha * A }
-//   colours : { g_alpha * A, g_k / ssum (k=0..2), sum_k g_k rgb_k / ssum, m }
-template <int MODE>
-__global__ __launch_bounds__(kThreads) void raster_prep_kernel(
-    DevParams P, const float *__restrict__ saved, const float *__restrict__ grad_rgba,
-    float *__restrict__ prep)
-{
-    const size_t idx = (size_t)blockIdx.x * kThreads + threadIdx.x;
-    const size_t npix = (size_t)P.S * P.S;
-    if (idx >= (size_t)P.B * npix) return;
-    const int b = (int)(idx / npix);
-    const int rem = (int)(idx - (size_t)b * npix);
-    const int row = rem / P.S, col = rem - row * P.S;
-    const int H = P.S / P.aa;
-    const float scale = P.aa == 2 ? 0.25f : 1.f;
-    const size_t plane = (size_t)H * H;
-    const size_t g = ((size_t)b * 4 * H + row / P.aa) * H + col / P.aa;
-    const float ga = grad_rgba[g + 3 * plane] * scale;
-    if (MODE == SV3D_TEX_NONE) {
-        prep[idx] = ga * saved[idx];
-    } else {
-        const float g0 = grad_rgba[g] * scale, g1 = grad_rgba[g + plane] * scale,
-                    g2 = grad_rgba[g + 2 * plane] * scale;
-        const float2 *sp = (const float2 *)(saved + idx * 6);
-        const float2 s0 = sp[0], s1 = sp[1], s2 = sp[2];      // (A, ssum) (m, r) (g, b)
-        const float is = 1.f / s0.y;
-        float2 *pp = (float2 *)(prep + idx * 6);
-        pp[0] = make_float2(ga * s0.x, g0 * is);
-        pp[1] = make_float2(g1 * is, g2 * is);
-        pp[2] = make_float2((g0 * s1.y + g1 * s2.x + g2 * s2.y) * is, s1.x);
-    }
-}
-
 template <int CTRL, int ROW_MASK>
 __device__ inline float dpp_add(float v)
 {
@@ -630,13 +596,13 @@ __device__ inline float wave_sum(float v)
     return (a + b) + (c + d);
 }
 
-// `prep`: colour modes read the folded per-pixel gradient written by raster_prep_kernel;
-// silhouette mode folds on the fly (g_alpha * A needs one value of each array), which saves a
-// launch: there `prep` is the saved A array and `galpha` the alpha plane of the incoming gradient.
+// `saved` are the forward's per-raster-pixel aggregates (1 float in silhouette mode, 6 in the
+// colour modes) and `grad_rgba` the incoming gradient at output resolution; both are folded per
+// visit, so there is no per-pixel preparation pass and no scratch buffer.
 template <int MODE>
 __global__ __launch_bounds__(kThreads) void raster_backward_kernel(
     DevParams P, const float4 *__restrict__ rec, const uint2 *__restrict__ pbox,
-    const float *__restrict__ tex, const float *__restrict__ prep, const float *__restrict__ galpha,
+    const float *__restrict__ tex, const float *__restrict__ saved, const float *__restrict__ grad_rgba,
     float *__restrict__ gfv, float *__restrict__ gtex)
 {
     extern __shared__ float s_dyn[];            // SURFACE: 4 x (R*R*3) texel accumulators
@@ -677,9 +643,8 @@ __global__ __launch_bounds__(kThreads) void raster_backward_kernel(
     const float step = 2.f / (float)S;
     float xp0, yp0;
     pixel_centre(col0, row0, S, xp0, yp0);
-    const float *prep_b = prep + (size_t)b * S * S * (MODE == SV3D_TEX_NONE ? 1 : 6);
+    const float *saved_b = saved + (size_t)b * S * S * (MODE == SV3D_TEX_NONE ? 1 : 6);
     const int H = S / P.aa;
-    const float *galpha_b = MODE == SV3D_TEX_NONE ? galpha + ((size_t)b * 4 + 3) * H * H : nullptr;
     const float gscale = P.aa == 2 ? 0.25f : 1.f;
     const float adv_y = bw > 0 ? (float)(64 / bw) : 0.f, adv_x = bw > 0 ? (float)(64 % bw) : 0.f;
     float ry_f = floorf(((float)lane + 0.5f) * inv_bw);
@@ -687,10 +652,16 @@ __global__ __launch_bounds__(kThreads) void raster_backward_kernel(
     if (rx_f < 0.f) { ry_f -= 1.f; rx_f += bw_f; }
     if (rx_f >= bw_f) { ry_f += 1.f; rx_f -= bw_f; }
 
+    // Raw per-pixel inputs: the forward's saved aggregates and the incoming gradient.  They are
+    // combined where they are used, so that the loads stay in flight across a step.
     struct PixIn {
-        float xp, yp, P0, G0, G1, G2, Rr, mfin;
+        float xp, yp;
+        float A, ssum, m, cr, cg, cb;       // saved: 1 - alpha product, softmax sum, max, RGB
+        float ga, g0, g1, g2;               // dL/d(alpha, R, G, B) of the output pixel
         bool valid;
     };
+    const size_t plane = (size_t)H * H;
+    const float *grad_b = grad_rgba + (size_t)b * 4 * plane;     // RGBA planes of image b
     auto fetch = [&]() {                            // inputs of the pixel at the current (rx, ry)
         PixIn in;
         in.valid = ry_f < bh_f;
@@ -699,15 +670,16 @@ __global__ __launch_bounds__(kThreads) void raster_backward_kernel(
         in.yp = fmaf(-cy, step, yp0);
         const unsigned prow = (unsigned)(row0 + (int)cy), pcol = (unsigned)(col0 + (int)cx);
         const unsigned pix = prow * (unsigned)S + pcol;
-        in.G0 = in.G1 = in.G2 = in.Rr = in.mfin = 0.f;
+        const unsigned gpix = P.aa == 2 ? (prow >> 1) * (unsigned)H + (pcol >> 1) : pix;
+        in.ssum = in.m = in.cr = in.cg = in.cb = in.g0 = in.g1 = in.g2 = 0.f;
+        in.ga = grad_b[gpix + 3 * plane];
         if (MODE == SV3D_TEX_NONE) {
-            const unsigned gpix = P.aa == 2 ? (prow >> 1) * (unsigned)H + (pcol >> 1) : pix;
-            in.P0 = prep_b[pix];                    // multiplied at the point of use so that
-            in.G0 = galpha_b[gpix];                 // the loads stay in flight across a step
+            in.A = saved_b[pix];
         } else {
-            const float2 *pp = (const float2 *)(prep_b + pix * 6u);
-            const float2 a0 = pp[0], a1 = pp[1], a2 = pp[2];
-            in.P0 = a0.x; in.G0 = a0.y; in.G1 = a1.x; in.G2 = a1.y; in.Rr = a2.x; in.mfin = a2.y;
+            const float2 *sp = (const float2 *)(saved_b + pix * 6u);
+            const float2 a0 = sp[0], a1 = sp[1], a2 = sp[2];
+            in.A = a0.x; in.ssum = a0.y; in.m = a1.x; in.cr = a1.y; in.cg = a2.x; in.cb = a2.y;
+            in.g0 = grad_b[gpix]; in.g1 = grad_b[gpix + plane]; in.g2 = grad_b[gpix + 2 * plane];
         }
         // advance to the pixel 64 positions further
         rx_f += adv_x;
@@ -725,11 +697,19 @@ __global__ __launch_bounds__(kThreads) void raster_backward_kernel(
         if (base + 64 < npix) nxt = fetch();        // wave-uniform
         const float xp = in.xp, yp = in.yp;
         const bool valid = in.valid;
-        const float G0 = in.G0, G1 = in.G1, G2 = in.G2, Rr = in.Rr, mfin = in.mfin;
+        // fold the gradient with the aggregates: g_alpha A, g_k / ssum, sum_k g_k rgb_k / ssum
+        const float P0 = in.A * (in.ga * gscale);
+        float G0 = 0.f, G1 = 0.f, G2 = 0.f, Rr = 0.f;
+        const float mfin = in.m;
+        if (MODE != SV3D_TEX_NONE) {
+            float is = rcp(in.ssum);
+            is = is * (2.f - in.ssum * is) * gscale;
+            G0 = in.g0 * is; G1 = in.g1 * is; G2 = in.g2 * is;
+            Rr = G0 * in.cr + G1 * in.cg + G2 * in.cb;
+        }
 
         PairGeom g = pair_geom(r, xp, yp, P);
         const bool act = valid && g.act;
-        const float P0 = MODE == SV3D_TEX_NONE ? in.P0 * (in.G0 * gscale) : in.P0;
         float gx = act ? P0 * g.D : 0.f;        // dL/dx, x = +-d2/sigma, through alpha
 
         if (MODE != SV3D_TEX_NONE) {
@@ -857,10 +837,10 @@ int make_dev_params(const sv3d_raster_params *p, DevParams &d)
 
 inline size_t rec_floats(const DevParams &d) { return (size_t)d.B * d.F * kRec; }
 inline int saved_per_pixel(const DevParams &d) { return d.mode == SV3D_TEX_NONE ? 1 : 6; }
-inline size_t backward_ws_need(const DevParams &d)
+inline size_t backward_ws_need(const DevParams &)
 {
-    // the silhouette backward folds the incoming gradient on the fly and needs no scratch
-    return d.mode == SV3D_TEX_NONE ? 0 : (size_t)d.B * d.S * d.S * 6 * sizeof(float);
+    // the backward folds the incoming gradient with the saved aggregates on the fly
+    return 0;
 }
 
 inline int launch_status()
@@ -943,31 +923,23 @@ int raster_backward_impl(const sv3d_raster_params *p, const float *textures, con
     if (st != SV3D_OK) return st;
     if (!face_rec || !pixel_saved || !grad_rgba || !grad_face_vertices) return SV3D_ERR_INVALID_ARG;
     if (d.mode != SV3D_TEX_NONE && !textures) return SV3D_ERR_INVALID_ARG;
-    const size_t need = backward_ws_need(d);
-    if (need > 0 && (!workspace || workspace_bytes < need)) return SV3D_ERR_WORKSPACE;
+    (void)workspace; (void)workspace_bytes;      // no mode needs scratch (sv3d_raster_sizes reports 0)
     hipStream_t s = static_cast<hipStream_t>(stream);
     const float4 *rec = static_cast<const float4 *>(face_rec);
     const uint2 *pbox = reinterpret_cast<const uint2 *>(static_cast<const float *>(face_rec) + rec_floats(d));
     const float *saved = static_cast<const float *>(pixel_saved);
-    float *prep = static_cast<float *>(workspace);
-    const size_t npix = (size_t)d.B * d.S * d.S;
-    const dim3 pgrid((unsigned)((npix + kThreads - 1) / kThreads)), block(kThreads);
-    const dim3 fgrid((d.B * d.F + 3) / 4);
+    const dim3 fgrid((d.B * d.F + 3) / 4), block(kThreads);
+    if (ev_start) (void)hipEventRecord(ev_start, s);
     if (d.mode == SV3D_TEX_NONE) {
-        if (ev_start) (void)hipEventRecord(ev_start, s);
         hipLaunchKernelGGL(raster_backward_kernel<SV3D_TEX_NONE>, fgrid, block, 0, s, d, rec, pbox,
                            textures, saved, grad_rgba, grad_face_vertices, (float *)nullptr);
     } else if (d.mode == SV3D_TEX_SURFACE) {
         const size_t lds = (size_t)4 * d.R * d.R * 3 * sizeof(float);
-        hipLaunchKernelGGL(raster_prep_kernel<SV3D_TEX_SURFACE>, pgrid, block, 0, s, d, saved, grad_rgba, prep);
-        if (ev_start) (void)hipEventRecord(ev_start, s);
         hipLaunchKernelGGL(raster_backward_kernel<SV3D_TEX_SURFACE>, fgrid, block, lds, s, d, rec, pbox,
-                           textures, prep, (const float *)nullptr, grad_face_vertices, grad_textures);
+                           textures, saved, grad_rgba, grad_face_vertices, grad_textures);
     } else {
-        hipLaunchKernelGGL(raster_prep_kernel<SV3D_TEX_VERTEX>, pgrid, block, 0, s, d, saved, grad_rgba, prep);
-        if (ev_start) (void)hipEventRecord(ev_start, s);
         hipLaunchKernelGGL(raster_backward_kernel<SV3D_TEX_VERTEX>, fgrid, block, 0, s, d, rec, pbox,
-                           textures, prep, (const float *)nullptr, grad_face_vertices, grad_textures);
+                           textures, saved, grad_rgba, grad_face_vertices, grad_textures);
     }
     if (ev_stop) (void)hipEventRecord(ev_stop, s);
     return launch_status();
