@@ -575,6 +575,16 @@ __global__ __launch_bounds__(kThreads) void raster_forward_kernel(
 // ------------------------------------------------------------------------------------
 // backward
 // ------------------------------------------------------------------------------------
+// LDS plan of the surface-texture backward, per wave (one face): `tex_tables` gradient tables of
+// Ts*3 floats and, when staged, Ts float4 texel values.
+__host__ __device__ inline int tex_tables(int Ts) { return Ts <= 64 ? 4 : 1; }
+__host__ __device__ inline bool tex_staged(int Ts) { return Ts <= 256; }
+__host__ __device__ inline int tex_grad_floats(int Ts) { return (tex_tables(Ts) * Ts * 3 + 3) & ~3; }
+__host__ __device__ inline int tex_lds_floats(int Ts)
+{
+    return tex_grad_floats(Ts) + (tex_staged(Ts) ? Ts * 4 : 0);      // both parts 16-byte multiples
+}
+
 template <int CTRL, int ROW_MASK>
 __device__ inline float dpp_add(float v)
 {
@@ -605,7 +615,7 @@ __global__ __launch_bounds__(kThreads) void raster_backward_kernel(
     const float *__restrict__ tex, const float *__restrict__ saved, const float *__restrict__ grad_rgba,
     float *__restrict__ gfv, float *__restrict__ gtex)
 {
-    extern __shared__ float s_dyn[];            // SURFACE: 4 x (R*R*3) texel accumulators
+    extern __shared__ float s_dyn[];            // SURFACE: per wave, texel gradient tables + texel values
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -620,11 +630,24 @@ __global__ __launch_bounds__(kThreads) void raster_backward_kernel(
     const int npix = (bw > 0 && bh > 0) ? bw * bh : 0;
     const float inv_bw = bw > 0 ? 1.f / (float)bw : 0.f;
 
+    // SURFACE: the face's texel gradients accumulate in wave-private LDS tables.  Lanes of one
+    // step mostly hit the same few texels, so small textures get four tables (lane & 3 picks one,
+    // summed in a fixed order at the end) to cut the serialisation of same-address adds; the
+    // face's texel values are staged beside them as float4 when they fit.
     const int Ts = P.R * P.R;
-    float *s_tex = s_dyn + wave * Ts * 3;
+    const int ncopy = tex_tables(Ts);
+    const bool staged = tex_staged(Ts);
+    float *s_tex = s_dyn + wave * tex_lds_floats(Ts);
+    float *s_val = s_tex + tex_grad_floats(Ts);
     float tv[9];
     if (MODE == SV3D_TEX_SURFACE) {
-        for (int i = lane; i < Ts * 3; i += 64) s_tex[i] = 0.f;
+        for (int i = lane; i < ncopy * Ts * 3; i += 64) s_tex[i] = 0.f;
+        if (staged) {
+            for (int i = lane; i < Ts; i += 64) {
+                const float *tp = tex + ((size_t)gf * Ts + i) * 3;
+                reinterpret_cast<float4 *>(s_val)[i] = make_float4(tp[0], tp[1], tp[2], 0.f);
+            }
+        }
     } else if (MODE == SV3D_TEX_VERTEX) {
 #pragma unroll
         for (int i = 0; i < 9; ++i) tv[i] = tex[(size_t)gf * 9 + i];
@@ -697,15 +720,14 @@ __global__ __launch_bounds__(kThreads) void raster_backward_kernel(
         if (base + 64 < npix) nxt = fetch();        // wave-uniform
         const float xp = in.xp, yp = in.yp;
         const bool valid = in.valid;
-        // fold the gradient with the aggregates: g_alpha A, g_k / ssum, sum_k g_k rgb_k / ssum
+        // fold the gradient with the aggregates: g_alpha A and g_k / ssum
         const float P0 = in.A * (in.ga * gscale);
-        float G0 = 0.f, G1 = 0.f, G2 = 0.f, Rr = 0.f;
+        float G0 = 0.f, G1 = 0.f, G2 = 0.f;
         const float mfin = in.m;
         if (MODE != SV3D_TEX_NONE) {
             float is = rcp(in.ssum);
             is = is * (2.f - in.ssum * is) * gscale;
             G0 = in.g0 * is; G1 = in.g1 * is; G2 = in.g2 * is;
-            Rr = G0 * in.cr + G1 * in.cg + G2 * in.cb;
         }
 
         PairGeom g = pair_geom(r, xp, yp, P);
@@ -721,14 +743,21 @@ __global__ __launch_bounds__(kThreads) void raster_backward_kernel(
                 int tid = 0;
                 if (MODE == SV3D_TEX_SURFACE) {
                     tid = texel_index(d.n0, d.n1, d.n2, P.R);
-                    const float *tp = tex + ((size_t)gf * Ts + tid) * 3;
-                    k0 = tp[0]; k1 = tp[1]; k2 = tp[2];
+                    if (staged) {
+                        const float4 tv4 = reinterpret_cast<const float4 *>(s_val)[tid];
+                        k0 = tv4.x; k1 = tv4.y; k2 = tv4.z;
+                    } else {
+                        const float *tp = tex + ((size_t)gf * Ts + tid) * 3;
+                        k0 = tp[0]; k1 = tp[1]; k2 = tp[2];
+                    }
                 } else {
                     k0 = d.n0 * tv[0] + d.n1 * tv[3] + d.n2 * tv[6];
                     k1 = d.n0 * tv[1] + d.n1 * tv[4] + d.n2 * tv[7];
                     k2 = d.n0 * tv[2] + d.n1 * tv[5] + d.n2 * tv[8];
                 }
-                const float S1 = G0 * k0 + G1 * k1 + G2 * k2 - Rr;
+                // sum_k g_k (colour_k - pixel_k) / ssum, differences first: where this face
+                // dominates the pixel the two colours nearly cancel
+                const float S1 = G0 * (k0 - in.cr) + G1 * (k1 - in.cg) + G2 * (k2 - in.cb);
                 const float De = g.D * ez;
                 gx += De * g.omD * S1;                               // through D of the softmax weight
                 const float gz = -(De * S1) * P.inv_gamma * P.inv_range;   // dL/dzp
@@ -740,9 +769,10 @@ __global__ __launch_bounds__(kThreads) void raster_backward_kernel(
                 float gn0 = -gz * zp2 * r.iz0, gn1 = -gz * zp2 * r.iz1, gn2 = -gz * zp2 * r.iz2;
                 if (MODE == SV3D_TEX_SURFACE) {
                     if (gtex != nullptr) {
-                        atomicAdd(&s_tex[tid * 3 + 0], gc0);
-                        atomicAdd(&s_tex[tid * 3 + 1], gc1);
-                        atomicAdd(&s_tex[tid * 3 + 2], gc2);
+                        float *slot = s_tex + ((lane & (ncopy - 1)) * Ts + tid) * 3;
+                        atomicAdd(slot + 0, gc0);
+                        atomicAdd(slot + 1, gc1);
+                        atomicAdd(slot + 2, gc2);
                     }
                 } else {
                     tacc[0] += d.n0 * gc0; tacc[1] += d.n0 * gc1; tacc[2] += d.n0 * gc2;
@@ -787,7 +817,11 @@ __global__ __launch_bounds__(kThreads) void raster_backward_kernel(
     }
     if (gtex != nullptr) {
         if (MODE == SV3D_TEX_SURFACE) {
-            for (int i = lane; i < Ts * 3; i += 64) gtex[(size_t)gf * Ts * 3 + i] = s_tex[i];
+            for (int i = lane; i < Ts * 3; i += 64) {
+                float t = s_tex[i];
+                for (int c = 1; c < ncopy; ++c) t += s_tex[c * Ts * 3 + i];
+                gtex[(size_t)gf * Ts * 3 + i] = t;
+            }
         } else if (MODE == SV3D_TEX_VERTEX) {
             float tt[9];
 #pragma unroll
@@ -934,7 +968,7 @@ int raster_backward_impl(const sv3d_raster_params *p, const float *textures, con
         hipLaunchKernelGGL(raster_backward_kernel<SV3D_TEX_NONE>, fgrid, block, 0, s, d, rec, pbox,
                            textures, saved, grad_rgba, grad_face_vertices, (float *)nullptr);
     } else if (d.mode == SV3D_TEX_SURFACE) {
-        const size_t lds = (size_t)4 * d.R * d.R * 3 * sizeof(float);
+        const size_t lds = (size_t)4 * tex_lds_floats(d.R * d.R) * sizeof(float);
         hipLaunchKernelGGL(raster_backward_kernel<SV3D_TEX_SURFACE>, fgrid, block, lds, s, d, rec, pbox,
                            textures, saved, grad_rgba, grad_face_vertices, grad_textures);
     } else {

@@ -76,7 +76,23 @@ def _hip(fv, tex, img, aa, mode, grad, unstable, **kw):
     return rgba.detach().cpu(), x.grad.cpu(), (t.grad.cpu() if t is not None else None)
 
 
-def _compare(name, fv, tex, img, aa, mode, **kw):
+def _fp32_floor(fv, tex, img, aa, mode, grad, unstable, want, wfv, wtex, **kw):
+    """Deviation of the oracle's own formulas evaluated in fp32 from their fp64 evaluation: what
+    single precision costs on this input before any kernel is involved (edge-on faces have
+    ill-conditioned barycentrics, which a sharp z-softmax amplifies)."""
+    S = img * (2 if aa else 1)
+    x = fv.float().requires_grad_(True)
+    t = tex.float().requires_grad_(True) if tex is not None else None
+    rgba, _ = raster_oracle.soft_rasterize(x, t, S, texture_mode=mode, **kw)
+    if aa:
+        rgba = torch.nn.functional.avg_pool2d(rgba, 2, 2)
+    (rgba * (grad * (~unstable)[:, None])).sum().backward()
+    keep = (~unstable)[:, None].expand_as(want)
+    return (float((rgba.detach().double() - want)[keep].abs().max() / want.abs().max()),
+            rel_err(x.grad, wfv), rel_err(t.grad, wtex) if wtex is not None else 0.0)
+
+
+def _compare(name, fv, tex, img, aa, mode, fp32_floor=False, grad_tol=None, **kw):
     B = fv.shape[0]
     grad = 2 * torch.rand(B, 4, img, img, generator=torch.Generator().manual_seed(4)) - 1
     want, wfv, wtex, unstable, nact = _oracle(fv, tex, img, aa, mode, grad, **kw)
@@ -90,7 +106,12 @@ def _compare(name, fv, tex, img, aa, mode, **kw):
     _record(name, img=e_img, grad_fv=e_fv, grad_tex=e_tex, unstable=frac, active=sum(nact))
     assert torch.isfinite(got).all() and torch.isfinite(gfv).all()
     sharp_softmax = mode != "none" and kw.get("gamma", 1e-4) <= 1e-4
-    gtol = COLOUR_GAMMA_1E4_TOL if sharp_softmax else GRAD_TOL
+    gtol = grad_tol if grad_tol is not None else (COLOUR_GAMMA_1E4_TOL if sharp_softmax else GRAD_TOL)
+    if fp32_floor:
+        # diagnostic only: how far the upstream-style formulas evaluated densely in fp32 stray
+        # from their fp64 evaluation on this input (recorded beside the kernel's own error)
+        itol, ftol, ttol = _fp32_floor(fv, tex, img, aa, mode, grad, unstable, want, wfv, wtex, **kw)
+        _record(name + "_fp32_oracle_floor", img=itol, grad_fv=ftol, grad_tex=ttol, unstable=frac, active=sum(nact))
     assert e_img < IMG_TOL, ("image", e_img)
     assert e_fv < gtol, ("grad_face_vertices", e_fv)
     assert e_tex < gtol, ("grad_textures", e_tex)
@@ -115,6 +136,21 @@ def test_parity_sigma_1e4_config(mode):
     fv = camera_space_faces(verts, faces, 2, seed=5)
     tex = _textures(mode, 2, faces.shape[0], 2)
     _compare("ico2_sigma1e-4_%s" % mode, fv, tex, 64, False, mode, sigma=1e-4)
+
+
+@pytest.mark.parametrize("R", [6, 9, 17])
+def test_parity_surface_texture_resolutions(R):
+    """The texture backward keeps texel tables in LDS in three layouts: four gradient tables plus
+    staged values (R*R <= 64: the reference's tex_size 6), one table plus staged values, and one
+    table with texel values read from memory (R*R > 256)."""
+    verts, faces = load_mesh(1)
+    fv = camera_space_faces(verts, faces, 2, seed=3)
+    tex = _textures("surface", 2, faces.shape[0], R)
+    # 80 large faces, several nearly edge-on: their fp32 barycentrics carry ~1e-5 of depth error,
+    # which gamma 1e-3 turns into ~3e-5 of colour-gradient error on those faces (a dense fp32
+    # evaluation of the upstream formulas is off by ~2e-3 here; it is recorded for comparison)
+    _compare("ico1_surface_R%d" % R, fv, tex, 48, False, "surface", fp32_floor=True, grad_tol=5e-5,
+             sigma=1e-4, gamma=1e-3)
 
 
 def test_parity_wide_softmax_and_single_sided():
