@@ -211,7 +211,7 @@ def test_c_abi_argument_validation_without_gpu():
     assert rec == 8 * 1280 * (32 * 4 + 8) and saved == 8 * 256 * 256 * 4 and ws == 0
     p.texture_mode = 1
     p.texture_res = 6
-    assert _lib.raster_sizes(p)[1:] == (8 * 256 * 256 * 6 * 4,) * 2
+    assert _lib.raster_sizes(p)[1:] == (8 * 256 * 256 * 6 * 4, 0)        # no backward scratch in any mode
     bad = _lib.make_params(0, 1280, 256, 1, 0, 1, True, (0, 0, 0), 1, 100, 1e-3, 1e-4, 1e-10, 1e-4)
     with pytest.raises(_lib.Sv3dError):
         _lib.raster_sizes(bad)
