@@ -13,7 +13,7 @@ weak and `value` is the sum over ranks.
 
 Prints ONE JSON line (rank 0).  `roofline` is for the kernel with the longest average
 launch (FP32 VALU bound; timed with HIP events recorded on the launch stream around that
-kernel in every timed step).  `cpu_baseline` is the dense fp32 torch evaluation of the same
+kernel on every 10th timed step).  `cpu_baseline` is the dense fp32 torch evaluation of the same
 formulas (oracle port) on the host cores, on a bounded sample.
 """
 import argparse

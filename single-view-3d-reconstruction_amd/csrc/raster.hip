@@ -619,7 +619,14 @@ __global__ __launch_bounds__(kThreads) void raster_backward_kernel(
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int gf = blockIdx.x * 4 + wave;       // global face index b*F + f
+    // Workgroups are handed to the 8 XCDs round-robin and each XCD has its own L2.  Consecutive
+    // faces read overlapping pixels of one image, so the launch order is permuted to give every
+    // XCD a contiguous range of faces: an image's pixels then miss in one L2 instead of eight.
+    // Small batches keep the plain order: with one or two images per XCD the images' unequal
+    // work would unbalance the XCDs (measured: +1 us at batch 8, -2..5 % from batch 64 on).
+    const int nwg = gridDim.x, xcd = blockIdx.x & 7, per = nwg >> 3, rem = nwg & 7;
+    const int wg = P.B >= 32 ? xcd * per + min(xcd, rem) + (blockIdx.x >> 3) : blockIdx.x;
+    const int gf = wg * 4 + wave;               // global face index b*F + f
     if (gf >= P.B * P.F) return;                // whole wave; no block-level barrier is used
     const int b = gf / P.F;
     const int S = P.S;

@@ -326,3 +326,32 @@ def test_face_gather_scatter_matches_indexing():
         (ref * g.double()).sum().backward()
         assert rel_err(out.detach().cpu(), ref.detach().cpu()) < 1e-6
         assert rel_err(x.grad.cpu(), y.grad.cpu()) < 1e-6
+
+
+@pytest.mark.parametrize("mode", ["none", "vertex"])
+def test_large_batch_launch_order_gives_identical_results(mode):
+    """From batch 32 on the backward permutes its workgroup order per XCD; every face is still
+    handled exactly once, so a batch of 35 must equal its images rendered in small batches, bit
+    for bit (35 * 80 faces: a workgroup count that is not a multiple of 8)."""
+    import sv3d
+    verts, faces = load_mesh(1)
+    B = 35
+    fv = camera_space_faces(verts, faces, B, seed=21).cuda()
+    tex = _textures(mode, B, faces.shape[0], 1)
+    tex = tex.cuda() if tex is not None else None
+    g = (2 * torch.rand(B, 4, 24, 24, generator=torch.Generator().manual_seed(6)) - 1).cuda()
+
+    def run(lo, hi):
+        x = fv[lo:hi].clone().requires_grad_(True)
+        t = tex[lo:hi].clone().requires_grad_(True) if tex is not None else None
+        out = sv3d.soft_rasterize(x, t, 24, texture_type="vertex", sigma_val=1e-4)
+        (out * g[lo:hi]).sum().backward()
+        return out.detach(), x.grad, (t.grad if t is not None else None)
+
+    whole = run(0, B)
+    parts = [run(lo, min(lo + 7, B)) for lo in range(0, B, 7)]
+    assert torch.equal(whole[0], torch.cat([p[0] for p in parts]))
+    assert torch.equal(whole[1], torch.cat([p[1] for p in parts]))
+    if tex is not None:
+        assert torch.equal(whole[2], torch.cat([p[2] for p in parts]))
+    assert whole[1].abs().max() > 0

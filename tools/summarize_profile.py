@@ -56,6 +56,10 @@ for k, v in rows.items():
         d["hbm_write_bytes"] = d["WRITE_SIZE"] * 1024
     if "SQ_INSTS_VALU" in d and "avg_ns" in d:
         d["valu_inst_per_ns_per_simd"] = d["SQ_INSTS_VALU"] / d["avg_ns"] / 1024.0
+    if "SQ_ACTIVE_INST_VALU" in d and "SQ_BUSY_CYCLES" in d and d["SQ_BUSY_CYCLES"]:
+        # SQ_ACTIVE_INST_VALU counts cycles (x4 per quad-cycle tick) a VALU instruction is executing,
+        # summed over SIMDs; SQ_BUSY_CYCLES is per shader engine.  Reported as the raw ratio.
+        d["valu_active_per_busy_cycle"] = d["SQ_ACTIVE_INST_VALU"] / d["SQ_BUSY_CYCLES"]
     if "SQ_WAVE_CYCLES" in d and d["SQ_WAVE_CYCLES"]:
         d["wait_any_frac"] = d.get("SQ_WAIT_ANY", 0) / d["SQ_WAVE_CYCLES"]
         d["wait_issue_frac"] = d.get("SQ_WAIT_INST_ANY", 0) / d["SQ_WAVE_CYCLES"]
