@@ -186,7 +186,10 @@ def rasterize_image(fv, tex, S, **kw):
         # ---- depth ---------------------------------------------------------------------
         wc = w.clamp(0.0, 1.0)
         wc = wc / wc.sum(-1, keepdim=True).clamp(min=1e-5)
-        zp = 1.0 / (wc / pz[None]).sum(-1)                      # [P,F]
+        den = (wc / pz[None]).sum(-1)
+        # pairs that take no part keep a finite depth (a face without area has w == 0 and would
+        # put 1/0 -- and through it NaN gradients -- into branches that are masked out below)
+        zp = 1.0 / torch.where(active, den, torch.ones_like(den))   # [P,F]
         zok = (zp.detach() >= near) & (zp.detach() <= far)
         front = ((py[:, 2] - py[:, 0]) * (px[:, 1] - px[:, 0]) <
                  (py[:, 1] - py[:, 0]) * (px[:, 2] - px[:, 0])).detach()

@@ -209,6 +209,16 @@ __device__ inline int texel_index(float n0, float n1, float n2, int R)
 // ------------------------------------------------------------------------------------
 // setup
 // ------------------------------------------------------------------------------------
+// ax*by - ay*bx with both products rounded before the subtraction: no fma contraction, so equal
+// products cancel to exactly 0.
+__device__ inline float cross_rounded(float ax, float ay, float bx, float by)
+{
+#pragma clang fp contract(off)
+    const float u = ax * by;
+    const float v = ay * bx;
+    return u - v;
+}
+
 // Record of face `gid` from its three camera-space corners; zref = z of the image's first corner.
 __device__ inline void setup_face(const DevParams &P, int gid, float x0, float y0, float z0, float x1,
                                   float y1, float z1, float x2, float y2, float z2, float zref,
@@ -218,7 +228,9 @@ __device__ inline void setup_face(const DevParams &P, int gid, float x0, float y
     const float e1x = x2 - x1, e1y = y2 - y1;
     const float e2x = x0 - x2, e2y = y0 - y2;
     const float l0 = e0x * e0x + e0y * e0y, l1 = e1x * e1x + e1y * e1y, l2 = e2x * e2x + e2y * e2y;
-    const float raw_det = e0x * (y2 - y0) - e0y * (x2 - x0);
+    // both products rounded before the subtraction (no fma contraction), so that a face with two
+    // equal corners gets exactly 0
+    const float raw_det = cross_rounded(e0x, e0y, x2 - x0, y2 - y0);
     const float det = raw_det > 0.f ? fmaxf(raw_det, 1e-10f) : fminf(raw_det, -1e-10f);
     const float bx0 = fminf(x0, fminf(x1, x2)) - P.margin, bx1 = fmaxf(x0, fmaxf(x1, x2)) + P.margin;
     const float by0 = fminf(y0, fminf(y1, y2)) - P.margin, by1 = fmaxf(y0, fmaxf(y1, y2)) + P.margin;
@@ -233,7 +245,11 @@ __device__ inline void setup_face(const DevParams &P, int gid, float x0, float y
     int yi0 = max((int)cy0, 0), yi1 = min((int)cy1, P.S - 1);
     int row0 = P.S - 1 - yi1, row1 = P.S - 1 - yi0;
     const bool finite = (bx0 == bx0) && (bx1 == bx1) && (by0 == by0) && (by1 == by1);
-    if (!finite || col0 > col1 || row0 > row1) {
+    // A face whose projected area is below the clamp on the determinant (a point, a segment, an
+    // exactly edge-on face) has no barycentric coordinates: upstream's algebra then yields
+    // distances of the order 1/1e-10 and the face shows nowhere.  It is dropped here.
+    const bool no_area = fabsf(raw_det) < 1e-10f;
+    if (!finite || no_area || col0 > col1 || row0 > row1) {
         col0 = 32767; col1 = -1; row0 = 32767; row1 = -1;
     }
     const uint2 box = make_uint2((uint32_t)(col0 & 0xffff) | ((uint32_t)(col1 & 0xffff) << 16),

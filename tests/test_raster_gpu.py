@@ -355,3 +355,26 @@ def test_large_batch_launch_order_gives_identical_results(mode):
     if tex is not None:
         assert torch.equal(whole[2], torch.cat([p[2] for p in parts]))
     assert whole[1].abs().max() > 0
+
+
+@pytest.mark.parametrize("mode", ["none", "surface"])
+def test_degenerate_faces_match_oracle_and_stay_finite(mode):
+    """Faces collapsed to a point, to a segment, or exactly edge-on (zero projected area, zero-length
+    edges) among ordinary faces: upstream's barycentric algebra divides by the clamped determinant
+    1e-10 there and such a face shows nowhere; the kernels drop it.  A face with three collinear
+    corners (area of rounding size, ties between its overlapping edges) must at least stay finite."""
+    import sv3d
+    verts, faces = load_mesh(1)
+    fv = camera_space_faces(verts, faces, 2, seed=12)
+    fv[0, 0, 1] = fv[0, 0, 0]; fv[0, 0, 2] = fv[0, 0, 0]                      # point
+    fv[0, 1, 2] = fv[0, 1, 1]                                                  # segment
+    fv[1, 3, 1, :2] = fv[1, 3, 0, :2]                                          # edge-on: same xy, other depth
+    tex = _textures(mode, 2, faces.shape[0], 2)
+    _compare("ico1_degenerate_%s" % mode, fv, tex, 32, False, mode, sigma=1e-4, gamma=1e-2)
+    fv[1, 2, 2] = 0.5 * (fv[1, 2, 0] + fv[1, 2, 1])                            # collinear
+    x = fv.cuda().requires_grad_(True)
+    t = tex.cuda().requires_grad_(True) if tex is not None else None
+    out = sv3d.soft_rasterize(x, t, 32, sigma_val=1e-4, gamma_val=1e-2)
+    out.sum().backward()
+    assert torch.isfinite(out).all() and torch.isfinite(x.grad).all()
+    assert t is None or torch.isfinite(t.grad).all()
