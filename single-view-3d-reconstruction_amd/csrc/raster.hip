@@ -235,12 +235,14 @@ __device__ inline void setup_face(const DevParams &P, int gid, float x0, float y
     const float bx0 = fminf(x0, fminf(x1, x2)) - P.margin, bx1 = fmaxf(x0, fmaxf(x1, x2)) + P.margin;
     const float by0 = fminf(y0, fminf(y1, y2)) - P.margin, by1 = fmaxf(y0, fmaxf(y1, y2)) + P.margin;
 
-    // pixel box: every pixel whose centre can pass the float cull test, widened by one
+    // pixel box: the pixels whose centre lies inside the cull box.  A pixel outside it is farther
+    // than the margin from the face, hence inactive, so the box bounds the work exactly; 0.01 pixel
+    // of slack covers the rounding of the conversion (below 1e-3 pixel up to the largest S).
     const float fs = (float)P.S, hi = fs;
-    const float cx0 = floorf(fminf(fmaxf((fs * bx0 + fs - 1.f) * 0.5f, -2.f), hi)) - 1.f;
-    const float cx1 = ceilf(fminf(fmaxf((fs * bx1 + fs - 1.f) * 0.5f, -2.f), hi)) + 1.f;
-    const float cy0 = floorf(fminf(fmaxf((fs * by0 + fs - 1.f) * 0.5f, -2.f), hi)) - 1.f;
-    const float cy1 = ceilf(fminf(fmaxf((fs * by1 + fs - 1.f) * 0.5f, -2.f), hi)) + 1.f;
+    const float cx0 = ceilf(fminf(fmaxf((fs * bx0 + fs - 1.f) * 0.5f, -2.f), hi) - 0.01f);
+    const float cx1 = floorf(fminf(fmaxf((fs * bx1 + fs - 1.f) * 0.5f, -2.f), hi) + 0.01f);
+    const float cy0 = ceilf(fminf(fmaxf((fs * by0 + fs - 1.f) * 0.5f, -2.f), hi) - 0.01f);
+    const float cy1 = floorf(fminf(fmaxf((fs * by1 + fs - 1.f) * 0.5f, -2.f), hi) + 0.01f);
     int col0 = max((int)cx0, 0), col1 = min((int)cx1, P.S - 1);
     int yi0 = max((int)cy0, 0), yi1 = min((int)cy1, P.S - 1);
     int row0 = P.S - 1 - yi1, row1 = P.S - 1 - yi0;
