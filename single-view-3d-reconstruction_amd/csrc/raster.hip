@@ -69,6 +69,7 @@ struct DevParams {
     float inv_gamma;
     float inv_range;              // 1 / (far - near)
     float ssum0;                  // exp(eps / gamma): weight of the background term
+    float inv_S;                  // 1 / S
 };
 
 // Face record layout (float index):
@@ -112,11 +113,10 @@ __device__ inline float ex2(float x) { return __builtin_amdgcn_exp2f(x); }
 __device__ inline float rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 
 // Pixel centre in normalised device coordinates; row 0 is the top of the image.
-__device__ inline void pixel_centre(int col, int row, int S, float &xp, float &yp)
+__device__ inline void pixel_centre(int col, int row, int S, float inv_S, float &xp, float &yp)
 {
-    const float fs = (float)S;
-    xp = (float)(2 * col + 1 - S) / fs;
-    yp = (float)(2 * (S - 1 - row) + 1 - S) / fs;
+    xp = (float)(2 * col + 1 - S) * inv_S;
+    yp = (float)(2 * (S - 1 - row) + 1 - S) * inv_S;
 }
 
 // Everything about one (pixel, face) pair that does not depend on colours.
@@ -382,11 +382,11 @@ __global__ __launch_bounds__(kThreads) void raster_forward_kernel(
     const int col = blk_c0 + (quad & 3) * 2 + (sub & 1);
     const int row = blk_r0 + (quad >> 2) * 2 + (sub >> 1);
     float xp, yp;
-    pixel_centre(col, row, S, xp, yp);
+    pixel_centre(col, row, S, P.inv_S, xp, yp);
     // NDC extent of the pixel centres of this wave's block
     float bxa, bxb, bya, byb;
-    pixel_centre(blk_c0, blk_r0 + 7, S, bxa, bya);
-    pixel_centre(blk_c0 + 7, blk_r0, S, bxb, byb);
+    pixel_centre(blk_c0, blk_r0 + 7, S, P.inv_S, bxa, bya);
+    pixel_centre(blk_c0 + 7, blk_r0, S, P.inv_S, bxb, byb);
 
     const float4 *rec_b = rec + (size_t)b * F * kRec4;
     const uint2 *pbox_b = pbox + (size_t)b * F;
@@ -610,18 +610,16 @@ __device__ inline float dpp_add(float v)
     return v + __int_as_float(moved);
 }
 
-// Sum over the 64 lanes with a fixed tree; the result is returned in every lane.
-__device__ inline float wave_sum(float v)
+// Sum over the 64 lanes with a fixed tree; the total is valid in lane 63 only.
+__device__ inline float wave_sum_lane63(float v)
 {
     v = dpp_add<0xB1, 0xf>(v);      // quad_perm [1,0,3,2]
     v = dpp_add<0x4E, 0xf>(v);      // quad_perm [2,3,0,1]
     v = dpp_add<0x141, 0xf>(v);     // row_half_mirror
     v = dpp_add<0x140, 0xf>(v);     // row_mirror: every lane of a row holds the row sum
-    const float a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
-    const float b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
-    const float c = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
-    const float d = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
-    return (a + b) + (c + d);
+    v = dpp_add<0x142, 0xa>(v);     // row_bcast:15: rows 1 and 3 add the row before them
+    v = dpp_add<0x143, 0xc>(v);     // row_bcast:31: rows 2 and 3 add rows 0+1
+    return v;
 }
 
 // `saved` are the forward's per-raster-pixel aggregates (1 float in silhouette mode, 6 in the
@@ -653,7 +651,7 @@ __global__ __launch_bounds__(kThreads) void raster_backward_kernel(
     unpack_box(pbox[gf], col0, col1, row0, row1);
     const int bw = col1 - col0 + 1, bh = row1 - row0 + 1;
     const int npix = (bw > 0 && bh > 0) ? bw * bh : 0;
-    const float inv_bw = bw > 0 ? 1.f / (float)bw : 0.f;
+    const float inv_bw = bw > 0 ? rcp((float)bw) : 0.f;     // the two fix-ups below absorb its last-bit error
 
     // SURFACE: the face's texel gradients accumulate in wave-private LDS tables.  Lanes of one
     // step mostly hit the same few texels, so small textures get four tables (lane & 3 picks one,
@@ -688,9 +686,9 @@ __global__ __launch_bounds__(kThreads) void raster_backward_kernel(
     // row wrap per lane; the per-pixel inputs of step i+1 are requested before step i is
     // evaluated so that their latency overlaps the arithmetic.
     const float bw_f = (float)bw, bh_f = (float)bh;
-    const float step = 2.f / (float)S;
+    const float step = 2.f * P.inv_S;
     float xp0, yp0;
-    pixel_centre(col0, row0, S, xp0, yp0);
+    pixel_centre(col0, row0, S, P.inv_S, xp0, yp0);
     const float *saved_b = saved + (size_t)b * S * S * (MODE == SV3D_TEX_NONE ? 1 : 6);
     const int H = S / P.aa;
     const float gscale = P.aa == 2 ? 0.25f : 1.f;
@@ -834,8 +832,9 @@ __global__ __launch_bounds__(kThreads) void raster_backward_kernel(
 
     float tot[9];
 #pragma unroll
-    for (int i = 0; i < 9; ++i) tot[i] = wave_sum(acc[i]);
-    if (lane == 0) {
+    for (int i = 0; i < 9; ++i)                     // silhouettes carry no depth gradient
+        tot[i] = (MODE == SV3D_TEX_NONE && i % 3 == 2) ? 0.f : wave_sum_lane63(acc[i]);
+    if (lane == 63) {
         float *o = gfv + (size_t)gf * 9;
 #pragma unroll
         for (int i = 0; i < 9; ++i) o[i] = tot[i];
@@ -850,8 +849,8 @@ __global__ __launch_bounds__(kThreads) void raster_backward_kernel(
         } else if (MODE == SV3D_TEX_VERTEX) {
             float tt[9];
 #pragma unroll
-            for (int i = 0; i < 9; ++i) tt[i] = wave_sum(tacc[i]);
-            if (lane == 0) {
+            for (int i = 0; i < 9; ++i) tt[i] = wave_sum_lane63(tacc[i]);
+            if (lane == 63) {
 #pragma unroll
                 for (int i = 0; i < 9; ++i) gtex[(size_t)gf * 9 + i] = tt[i];
             }
@@ -891,6 +890,7 @@ int make_dev_params(const sv3d_raster_params *p, DevParams &d)
     d.inv_gamma = (float)(1.0 / (double)p->gamma);
     d.inv_range = (float)(1.0 / ((double)p->far_plane - (double)p->near_plane));
     d.ssum0 = (float)exp((double)p->eps / (double)p->gamma);
+    d.inv_S = (float)(1.0 / (double)p->raster_size);
     return SV3D_OK;
 }
 
