@@ -70,6 +70,7 @@ struct DevParams {
     float inv_range;              // 1 / (far - near)
     float ssum0;                  // exp(eps / gamma): weight of the background term
     float inv_S;                  // 1 / S
+    int alpha_fast;               // dist_eps so small that 1 + exp(-threshold/sigma) == 1 in fp32
 };
 
 // Face record layout (float index):
@@ -167,6 +168,31 @@ __device__ inline PairGeom pair_geom(const FaceRec &r, float xp, float yp, const
     g.D = g.act ? D : 0.f;
     g.omD = g.act ? e * D : 1.f;
     return g;
+}
+
+// 1 - D of a pair, all the silhouette forward needs.  With x = +-d2/sigma (+ inside),
+// 1 - D = 1 / (1 + exp(x)) directly: no cancellation, exp overflow gives exactly 0, and for an
+// outside pixel at or beyond the cull distance exp(x) <= dist_eps/(1-dist_eps) = 1e-10 is absorbed
+// by the 1 + ..., so the value is exactly 1 there -- the same as skipping the pair -- without
+// testing for it.  (Only taken when dist_eps is below half an fp32 ulp of 1: DevParams::alpha_fast.)
+__device__ inline float pair_one_minus_D(const FaceRec &r, float xp, float yp, const DevParams &P)
+{
+    const float a0x = r.p0x - xp, a0y = r.p0y - yp;
+    const float a1x = r.p1x - xp, a1y = r.p1y - yp;
+    const float a2x = r.p2x - xp, a2y = r.p2y - yp;
+    const float t0 = sat(-(a0x * r.e0x + a0y * r.e0y) * r.il0);
+    const float t1 = sat(-(a1x * r.e1x + a1y * r.e1y) * r.il1);
+    const float t2 = sat(-(a2x * r.e2x + a2y * r.e2y) * r.il2);
+    const float d0x = fmaf(t0, r.e0x, a0x), d0y = fmaf(t0, r.e0y, a0y);
+    const float d1x = fmaf(t1, r.e1x, a1x), d1y = fmaf(t1, r.e1y, a1y);
+    const float d2x = fmaf(t2, r.e2x, a2x), d2y = fmaf(t2, r.e2y, a2y);
+    const float d2 = fminf(d0x * d0x + d0y * d0y, fminf(d1x * d1x + d1y * d1y, d2x * d2x + d2y * d2y));
+    const float c0 = r.e0y * a0x - r.e0x * a0y;
+    const float c1 = r.e1y * a1x - r.e1x * a1y;
+    const float c2 = r.e2y * a2x - r.e2x * a2y;
+    const bool inside = (c1 * r.inv_det > 0.f) && (c2 * r.inv_det > 0.f) && (c0 * r.inv_det > 0.f);
+    const float e = ex2((inside ? d2 : -d2) * -P.neg_l2e_over_sigma);
+    return rcp(1.f + e);
 }
 
 // Depth and normalised clamped barycentrics of a pair.
@@ -440,6 +466,13 @@ __global__ __launch_bounds__(kThreads) void raster_forward_kernel(
                 const int jj = j0 + __builtin_ctzll(mask);
                 mask &= mask - 1;
                 const FaceRec r = load_rec(&s_rec[jj * kRecPad4]);
+                if (MODE == SV3D_TEX_NONE && P.alpha_fast) {
+                    A *= pair_one_minus_D(r, xp, yp, P);
+#ifdef SV3D_TRACE
+                    ++trace_visits;
+#endif
+                    continue;
+                }
                 const PairGeom g = pair_geom(r, xp, yp, P);
                 A *= g.omD;
 #ifdef SV3D_TRACE
@@ -891,6 +924,7 @@ int make_dev_params(const sv3d_raster_params *p, DevParams &d)
     d.inv_range = (float)(1.0 / ((double)p->far_plane - (double)p->near_plane));
     d.ssum0 = (float)exp((double)p->eps / (double)p->gamma);
     d.inv_S = (float)(1.0 / (double)p->raster_size);
+    d.alpha_fast = (double)p->dist_eps / (1.0 - (double)p->dist_eps) < 2.9e-8;   // below half an ulp of 1
     return SV3D_OK;
 }
 
