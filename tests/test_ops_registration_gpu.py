@@ -1,0 +1,55 @@
+"""The `sv3d::*` PyTorch custom ops are registered consistently: schema, fake (meta) kernels and
+autograd formulas agree with the real kernels (torch.library.opcheck), and the ops can be traced
+with fake tensors (what torch.compile and DDP's graph inspection rely on)."""
+import pytest
+import torch
+
+from helpers import load_mesh, random_cams, random_vertices
+
+pytestmark = pytest.mark.gpu
+
+TESTS = ("test_schema", "test_faketensor", "test_autograd_registration")
+
+
+def _mesh(B=2):
+    verts, faces = load_mesh(1)
+    return random_vertices(verts, B, 0).cuda(), random_cams(B, 1).cuda(), faces[None].cuda().contiguous()
+
+
+def test_opcheck_raster_and_render_ops():
+    from sv3d import ops
+    v, cams, f = _mesh()
+    fv = ops.project_gather(v, cams, f, 5.0, (1.0, -1.0, 1.0), (0.0, 0.0, 2.732))
+    tex = torch.rand(2, f.shape[1], 4, 3, device="cuda")
+    scal = (32, 1, 1, 2, True, [0.0, 0.0, 0.0], 1.0, 100.0, 1e-3, 1e-4, 1e-10, 1e-2)
+    torch.library.opcheck(ops.soft_rasterize_op, (fv.requires_grad_(True), tex.requires_grad_(True)) + scal,
+                          test_utils=TESTS)
+    torch.library.opcheck(ops.soft_rasterize_op, (fv, None, 32, 1, 0, 1, True, [0.0, 0.0, 0.0], 1.0, 100.0,
+                                                  1e-3, 1e-4, 1e-10, 1e-2), test_utils=TESTS)
+    torch.library.opcheck(ops.render_op, (v.requires_grad_(True), cams.requires_grad_(True), f, tex, 5.0,
+                                          [1.0, -1.0, 1.0], [0.0, 0.0, 2.732]) + scal, test_utils=TESTS)
+
+
+def test_opcheck_mesh_and_chamfer_ops():
+    from sv3d import ops
+    v, cams, f = _mesh()
+    torch.library.opcheck(ops.face_gather_op, (v.requires_grad_(True), f, [1.0, -1.0, 1.0], [0.0, 0.0, 1.0]),
+                          test_utils=TESTS)
+    torch.library.opcheck(ops.project_gather_op, (v, cams.requires_grad_(True), f, 5.0, [1.0, -1.0, 1.0],
+                                                  [0.0, 0.0, 2.732]), test_utils=TESTS)
+    a = torch.randn(2, 50, 3, device="cuda", requires_grad=True)
+    b = torch.randn(2, 70, 3, device="cuda", requires_grad=True)
+    torch.library.opcheck(ops.chamfer_nn_op, (a, b), test_utils=TESTS)
+
+
+def test_ops_trace_with_fake_tensors():
+    from torch._subclasses.fake_tensor import FakeTensorMode
+    import sv3d
+    with FakeTensorMode():
+        v = torch.empty(3, 642, 3, device="cuda")
+        cams = torch.empty(3, 7, device="cuda")
+        f = torch.empty(1, 1280, 3, dtype=torch.int32, device="cuda")
+        out = sv3d.render(v, cams, f, None, 64, anti_aliasing=True)
+        assert out.shape == (3, 4, 64, 64)
+        d1, d2, i1, i2 = sv3d.chamfer_nn(torch.empty(3, 10, 3, device="cuda"), torch.empty(3, 20, 3, device="cuda"))
+        assert d2.shape == (3, 20) and i1.dtype == torch.int32
