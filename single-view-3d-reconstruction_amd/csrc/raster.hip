@@ -643,6 +643,27 @@ __device__ inline float dpp_add(float v)
     return v + __int_as_float(moved);
 }
 
+// One merge step of the texel-gradient combine: lanes whose `bit` of the lane id is clear take
+// the values of lane + bit when both hold the same texel; the giving lane then holds none.
+// TAKE / GIVE are the DPP controls that read lane + bit / lane - bit (identical for the
+// symmetric quad permutations).  A source lane outside the row reads as "no texel".
+template <int TAKE, int GIVE, int BIT>
+__device__ inline void merge_texel_step(int &tid, float &g0, float &g1, float &g2, int lane)
+{
+    const bool taker = (lane & BIT) == 0;
+    const int up = __builtin_amdgcn_update_dpp(-1, tid, TAKE, 0xf, 0xf, false);
+    const int dn = TAKE == GIVE ? up : __builtin_amdgcn_update_dpp(-1, tid, GIVE, 0xf, 0xf, false);
+    const float p0 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(g0), TAKE, 0xf, 0xf, false));
+    const float p1 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(g1), TAKE, 0xf, 0xf, false));
+    const float p2 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(g2), TAKE, 0xf, 0xf, false));
+    const bool take = taker && up == tid;
+    const bool give = !taker && dn == tid;
+    g0 += take ? p0 : 0.f;
+    g1 += take ? p1 : 0.f;
+    g2 += take ? p2 : 0.f;
+    tid = give ? -2 - lane : tid;
+}
+
 // Sum over the 64 lanes with a fixed tree; the total is valid in lane 63 only.
 __device__ inline float wave_sum_lane63(float v)
 {
@@ -793,6 +814,9 @@ __global__ __launch_bounds__(kThreads) void raster_backward_kernel(
         if (MODE != SV3D_TEX_NONE) {
             const PairDepth d = pair_depth(r, g, P);
             const bool contrib = valid && d.contrib;
+            // SURFACE: this lane's texel and colour gradient, handed to the merge below
+            int ttid = -2 - lane;                   // negative ids are unique per lane: "no texel"
+            float tg0 = 0.f, tg1 = 0.f, tg2 = 0.f;
             if (contrib) {
                 const float ez = ex2((d.zn - mfin) * P.l2e_over_gamma);
                 float k0, k1, k2;
@@ -824,12 +848,7 @@ __global__ __launch_bounds__(kThreads) void raster_backward_kernel(
                 acc[8] += gz * zp2 * d.n2 * r.iz2 * r.iz2;
                 float gn0 = -gz * zp2 * r.iz0, gn1 = -gz * zp2 * r.iz1, gn2 = -gz * zp2 * r.iz2;
                 if (MODE == SV3D_TEX_SURFACE) {
-                    if (gtex != nullptr) {
-                        float *slot = s_tex + ((lane & (ncopy - 1)) * Ts + tid) * 3;
-                        atomicAdd(slot + 0, gc0);
-                        atomicAdd(slot + 1, gc1);
-                        atomicAdd(slot + 2, gc2);
-                    }
+                    ttid = tid; tg0 = gc0; tg1 = gc1; tg2 = gc2;
                 } else {
                     tacc[0] += d.n0 * gc0; tacc[1] += d.n0 * gc1; tacc[2] += d.n0 * gc2;
                     tacc[3] += d.n1 * gc0; tacc[4] += d.n1 * gc1; tacc[5] += d.n1 * gc2;
@@ -850,6 +869,21 @@ __global__ __launch_bounds__(kThreads) void raster_backward_kernel(
                 acc[0] -= g.w0 * Vx; acc[1] -= g.w0 * Vy;
                 acc[3] -= g.w1 * Vx; acc[4] -= g.w1 * Vy;
                 acc[6] -= g.w2 * Vx; acc[7] -= g.w2 * Vy;
+            }
+            if (MODE == SV3D_TEX_SURFACE && gtex != nullptr) {
+                // LDS float atomics retire about one lane per clock, and neighbouring lanes
+                // (neighbouring pixels of a row) mostly hit the same texel: lanes of an aligned
+                // group of 8 with equal texels are first merged into the lowest of them (fixed
+                // order), then only the lanes left holding a texel issue the adds.
+                merge_texel_step<0xB1, 0xB1, 1>(ttid, tg0, tg1, tg2, lane);     // quad_perm [1,0,3,2]
+                merge_texel_step<0x4E, 0x4E, 2>(ttid, tg0, tg1, tg2, lane);     // quad_perm [2,3,0,1]
+                merge_texel_step<0x104, 0x114, 4>(ttid, tg0, tg1, tg2, lane);   // row_shl:4 / row_shr:4
+                if (ttid >= 0) {
+                    float *slot = s_tex + ((lane & (ncopy - 1)) * Ts + ttid) * 3;
+                    atomicAdd(slot + 0, tg0);
+                    atomicAdd(slot + 1, tg1);
+                    atomicAdd(slot + 2, tg2);
+                }
             }
         }
         // through the distance: d2 = |foot - pixel|^2, foot = (1-t) p_k + t p_{k+1}
