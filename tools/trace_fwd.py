@@ -97,3 +97,19 @@ try:
         prev = np.where(ok, cur, prev)
 except AttributeError:
     pass
+if os.environ.get("SV3D_TRACE_PLACEMENT"):
+    # where the dispatcher put each workgroup: (xcc, se, sh, cu) per workgroup index
+    k0 = key[:, 0]
+    print("placement of workgroups 0..95 (xcc.se.sh.cu):")
+    for i0 in range(0, 96, 8):
+        print("  " + "  ".join("%d.%d.%d.%02d" % (xcc[i, 0], se[i, 0], sh[i, 0], cu[i, 0]) for i in range(i0, i0 + 8)))
+    # period: smallest d > 0 with key[i] == key[i + d] for most i among the first 1024
+    for d in (8, 16, 32, 64, 128, 256, 512, 1024):
+        if d < n:
+            print("  same CU at distance %4d: %.0f%%" % (d, 100.0 * np.mean(k0[: n - d] == k0[d:n])))
+    order = {}
+    for i in range(n):
+        order.setdefault(int(k0[i]), []).append(i)
+    some = list(order.items())[:6]
+    for kk, lst in some:
+        print("  CU key %d got workgroups %s" % (kk, lst))
