@@ -376,11 +376,17 @@ __device__ inline int wave_inclusive_scan(int v)
 // ------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------
-template <int MODE>
-__global__ __launch_bounds__(kThreads) void raster_forward_kernel(
+// SPLIT = 1: four waves, one per 8x8 block of the tile.  SPLIT = 2 (small grids): eight waves, two
+// per block, which take alternate hits of the block's face list and merge their partial pixel
+// states through LDS at the end -- the kernel's span at small batches is its longest single wave
+// (a silhouette-ring block with ~60 faces), and this halves it.
+template <int MODE, int SPLIT>
+__global__ __launch_bounds__(kThreads * SPLIT) void raster_forward_kernel(
     DevParams P, const float4 *__restrict__ rec, const uint2 *__restrict__ pbox,
     const float *__restrict__ tex, float *__restrict__ rgba, float *__restrict__ saved)
 {
+    constexpr int NT = kThreads * SPLIT;        // threads per workgroup
+    constexpr int NW = 4 * SPLIT;               // waves per workgroup
     __shared__ float4 s_rec[kListCap * kRecPad4];
     __shared__ int s_ids[kListCap];
     __shared__ unsigned long long s_mask[64];
@@ -404,7 +410,8 @@ __global__ __launch_bounds__(kThreads) void raster_forward_kernel(
     const int tile_c0 = ((tile % tiles_x + 5 * tile_y) % tiles_x) * kTile, tile_r0 = tile_y * kTile;
     // lane -> pixel of the wave's 8x8 block; lanes 4q..4q+3 form the 2x2 quad q
     const int quad = lane >> 2, sub = lane & 3;
-    const int blk_c0 = tile_c0 + (wave & 1) * 8, blk_r0 = tile_r0 + (wave >> 1) * 8;
+    const int blk = wave & 3, part = wave >> 2;         // block of the tile, share of its face list
+    const int blk_c0 = tile_c0 + (blk & 1) * 8, blk_r0 = tile_r0 + (blk >> 1) * 8;
     const int col = blk_c0 + (quad & 3) * 2 + (sub & 1);
     const int row = blk_r0 + (quad >> 2) * 2 + (sub >> 1);
     float xp, yp;
@@ -422,10 +429,12 @@ __global__ __launch_bounds__(kThreads) void raster_forward_kernel(
 #ifdef SV3D_TRACE
     int trace_visits = 0;
 #endif
+    const unsigned long long lane_lt = (1ull << lane) - 1ull;
     float A = 1.f;                              // prod (1 - D)
     float m = P.eps - c0shift;                  // running softmax maximum, shifted by c0shift
-    float ssum = P.ssum0;
+    float ssum = part == 0 ? P.ssum0 : 0.f;     // the background term enters once, through part 0
     float C0 = P.bg0 * ssum, C1 = P.bg1 * ssum, C2 = P.bg2 * ssum;
+    int hits_seen = 0;                          // hits of this block so far (wave-uniform)
 
     // Conservative per-(block, face) test run lane-parallel over list entries: the block can only
     // hold an active pixel if it overlaps the face's cull box AND no edge line has the whole
@@ -454,7 +463,7 @@ __global__ __launch_bounds__(kThreads) void raster_forward_kernel(
 
     auto process_list = [&](int n) {
         SV3D_STAMP(3);
-        for (int i = threadIdx.x; i < n * kRec4; i += kThreads)
+        for (int i = threadIdx.x; i < n * kRec4; i += NT)
             s_rec[(i / kRec4) * kRecPad4 + (i % kRec4)] = rec_b[(size_t)s_ids[i / kRec4] * kRec4 + (i % kRec4)];
         __syncthreads();
         SV3D_STAMP(4);
@@ -462,6 +471,11 @@ __global__ __launch_bounds__(kThreads) void raster_forward_kernel(
             const int j = j0 + lane;
             const bool hit = j < n && block_may_touch(&s_rec[min(j, n - 1) * kRecPad4]);
             unsigned long long mask = __ballot(hit);
+            if (SPLIT == 2) {                   // the block's hits alternate between its two waves
+                const bool mine = hit && (((hits_seen + __popcll(mask & lane_lt)) & 1) == part);
+                hits_seen += __popcll(mask);
+                mask = __ballot(mine);
+            }
             while (mask) {
                 const int jj = j0 + __builtin_ctzll(mask);
                 mask &= mask - 1;
@@ -516,20 +530,19 @@ __global__ __launch_bounds__(kThreads) void raster_forward_kernel(
     // mask popcounts for itself (DPP prefix sum, no second barrier), which gives each hit its
     // list position, and the list is consumed in windows of kListCap faces.
     const int tc1 = tile_c0 + kTile - 1, tr1 = tile_r0 + kTile - 1;
-    const unsigned long long lane_lt = (1ull << lane) - 1ull;
     SV3D_STAMP(0);
     for (int fbase = 0; fbase < F; fbase += 64 * 64) {
         const int nmask = (min(F - fbase, 64 * 64) + 63) >> 6;      // at most 64 masks per pass
-        for (int m0 = wave; m0 < nmask; m0 += 32) {                 // eight masks per wave per trip
+        for (int m0 = wave; m0 < nmask; m0 += 8 * NW) {             // eight masks per wave per trip
             uint2 bx[8];
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
-                const int f = fbase + (m0 + 4 * k) * 64 + lane;
+                const int f = fbase + (m0 + NW * k) * 64 + lane;
                 bx[k] = f < F ? pbox_b[f] : make_uint2(0xffff7fffu, 0xffff7fffu);   // empty box
             }
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
-                const int mi = m0 + 4 * k;
+                const int mi = m0 + NW * k;
                 if (mi < nmask) {                                   // wave-uniform
                     int c0, c1, r0, r1;
                     unpack_box(bx[k], c0, c1, r0, r1);
@@ -549,7 +562,7 @@ __global__ __launch_bounds__(kThreads) void raster_forward_kernel(
         const int excl = incl - my_cnt;
         SV3D_STAMP(2);
         for (int win = 0; win < total; win += kListCap) {
-            for (int mi = wave; mi < nmask; mi += 4) {
+            for (int mi = wave; mi < nmask; mi += NW) {
                 const unsigned long long mask = s_mask[mi];
                 const int off = __builtin_amdgcn_readlane(excl, mi);
                 if ((mask >> lane) & 1ull) {
@@ -561,6 +574,30 @@ __global__ __launch_bounds__(kThreads) void raster_forward_kernel(
             process_list(min(kListCap, total - win));
         }
         __syncthreads();
+    }
+
+    if (SPLIT == 2) {
+        // merge the two partial pixel states of every block (s_rec is free after the last barrier)
+        float *s_part = reinterpret_cast<float *>(s_rec) + (blk * 64 + lane) * 6;
+        if (part == 1) {
+            s_part[0] = A;
+            if (MODE != SV3D_TEX_NONE) {
+                s_part[1] = m; s_part[2] = ssum; s_part[3] = C0; s_part[4] = C1; s_part[5] = C2;
+            }
+        }
+        __syncthreads();
+        if (part == 1) return;
+        A *= s_part[0];
+        if (MODE != SV3D_TEX_NONE) {
+            const float m1 = s_part[1];
+            const float mn = fmaxf(m, m1);
+            const float sa = ex2((m - mn) * P.l2e_over_gamma), sb = ex2((m1 - mn) * P.l2e_over_gamma);
+            ssum = sa * ssum + sb * s_part[2];
+            C0 = sa * C0 + sb * s_part[3];
+            C1 = sa * C1 + sb * s_part[4];
+            C2 = sa * C2 + sb * s_part[5];
+            m = mn;
+        }
     }
 
     // epilogue
@@ -609,7 +646,7 @@ __global__ __launch_bounds__(kThreads) void raster_forward_kernel(
     }
     SV3D_STAMP(6);
 #ifdef SV3D_TRACE
-    if (lane == 0 && blockIdx.x < 4096) {
+    if (lane == 0 && blockIdx.x < 4096 && wave < 4) {
         unsigned hwid;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
         unsigned xcc;
@@ -1029,13 +1066,21 @@ int raster_forward_impl(const sv3d_raster_params *p, const float *face_vertices,
     dim3 grid((unsigned)tiles * tiles * d.B), block(kThreads);
     float *saved = static_cast<float *>(pixel_saved);
     if (ev_start) (void)hipEventRecord(ev_start, s);
-#define SV3D_FWD_KERNEL raster_forward_kernel
-    if (d.mode == SV3D_TEX_NONE)
-        hipLaunchKernelGGL(SV3D_FWD_KERNEL<SV3D_TEX_NONE>, grid, block, 0, s, d, rec, pbox, textures, rgba_out, saved);
-    else if (d.mode == SV3D_TEX_SURFACE)
-        hipLaunchKernelGGL(SV3D_FWD_KERNEL<SV3D_TEX_SURFACE>, grid, block, 0, s, d, rec, pbox, textures, rgba_out, saved);
-    else
-        hipLaunchKernelGGL(SV3D_FWD_KERNEL<SV3D_TEX_VERTEX>, grid, block, 0, s, d, rec, pbox, textures, rgba_out, saved);
+    // two waves per block while the grid is small enough that single waves set the kernel's span
+    const bool split = (long)tiles * tiles * d.B <= 4096;
+#define SV3D_LAUNCH_FWD(M)                                                                               \
+    do {                                                                                                 \
+        if (split)                                                                                       \
+            hipLaunchKernelGGL((raster_forward_kernel<M, 2>), grid, dim3(2 * kThreads), 0, s, d, rec, pbox, \
+                               textures, rgba_out, saved);                                               \
+        else                                                                                             \
+            hipLaunchKernelGGL((raster_forward_kernel<M, 1>), grid, block, 0, s, d, rec, pbox, textures, \
+                               rgba_out, saved);                                                         \
+    } while (0)
+    if (d.mode == SV3D_TEX_NONE) SV3D_LAUNCH_FWD(SV3D_TEX_NONE);
+    else if (d.mode == SV3D_TEX_SURFACE) SV3D_LAUNCH_FWD(SV3D_TEX_SURFACE);
+    else SV3D_LAUNCH_FWD(SV3D_TEX_VERTEX);
+#undef SV3D_LAUNCH_FWD
     if (ev_stop) (void)hipEventRecord(ev_stop, s);
     return launch_status();
 }
