@@ -33,8 +33,8 @@ import torch  # noqa: E402
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--batch", type=int, default=8, help="images per render batch per GPU")
     ap.add_argument("--image-size", type=int, default=256)
     ap.add_argument("--subdivide", type=int, default=3)
