@@ -173,6 +173,13 @@ def soft_rasterize(face_vertices, textures=None, image_size=256, *, anti_aliasin
         mode, res = L.SV3D_TEX_VERTEX, 1
     else:
         raise ValueError("unknown texture_type %r" % (texture_type,))
+    if _plain(face_vertices, textures) and face_vertices.is_cuda:
+        _check_raster_inputs(face_vertices, textures, mode, res)
+        key = (face_vertices.shape[0], face_vertices.shape[1], int(image_size) * aa, aa, mode, res,
+               bool(fill_back), tuple(float(c) for c in background_color), float(near), float(far),
+               float(eps), float(sigma_val), float(dist_eps), float(gamma_val))
+        return _RenderFn.apply(face_vertices, None, None, textures if mode != L.SV3D_TEX_NONE else None,
+                               None, key)
     rgba, _, _ = soft_rasterize_op(face_vertices, textures, int(image_size) * aa, aa, mode, res,
                                    bool(fill_back), [float(c) for c in background_color],
                                    float(near), float(far), float(eps), float(sigma_val),
@@ -256,6 +263,8 @@ chamfer_nn_op.register_autograd(_chamfer_backward, setup_context=_chamfer_setup_
 
 def chamfer_nn(xyz1, xyz2):
     """(dist1 [B,N], dist2 [B,M], idx1 [B,N] int32, idx2 [B,M] int32); squared distances."""
+    if _plain(xyz1, xyz2) and xyz1.is_cuda and xyz2.is_cuda:
+        return _ChamferFn.apply(xyz1, xyz2)
     return chamfer_nn_op(xyz1, xyz2)
 
 
@@ -525,8 +534,153 @@ def render(vertices, cams, faces, textures=None, image_size=256, *, offset_z=0.0
         mode, res = L.SV3D_TEX_VERTEX, 1
     else:
         raise ValueError("unknown texture_type %r" % (texture_type,))
-    rgba, _, _ = render_op(vertices, cams, _faces_i32(faces), textures, float(offset_z),
+    f32 = _faces_i32(faces)
+    if _plain(vertices, cams, textures) and vertices.is_cuda:
+        _check_mesh(vertices, cams, f32)
+        B, F = vertices.shape[0], f32.shape[1]
+        if mode != L.SV3D_TEX_NONE:
+            want = (B, F, res * res, 3) if mode == L.SV3D_TEX_SURFACE else (B, F, 3, 3)
+            if tuple(textures.shape) != want:
+                raise ValueError("textures must be %s" % (want,))
+        key = (B, F, int(image_size) * aa, aa, mode, res, bool(fill_back),
+               tuple(float(c) for c in background_color), float(near), float(far), float(eps),
+               float(sigma_val), float(dist_eps), float(gamma_val))
+        mesh_args = (float(offset_z), tuple(float(v) for v in scale), tuple(float(v) for v in shift))
+        return _RenderFn.apply(vertices, cams, f32, textures if mode != L.SV3D_TEX_NONE else None,
+                               mesh_args, key)
+    rgba, _, _ = render_op(vertices, cams, f32, textures, float(offset_z),
                            [float(s) for s in scale], [float(s) for s in shift], int(image_size) * aa, aa,
                            mode, res, bool(fill_back), [float(c) for c in background_color], float(near),
                            float(far), float(eps), float(sigma_val), float(dist_eps), float(gamma_val))
     return rgba
+
+
+# ---- eager fast path ------------------------------------------------------------------------
+# torch.library's Python dispatch costs 100-150 us per op call (schema handling, functionalisation
+# checks), more than the kernels themselves at small batches.  Outside of tracing the public
+# functions therefore go through plain autograd.Functions over the same C ABI calls; the registered
+# ops above stay the route for torch.compile / fake-tensor tracing.  Both routes run the same
+# kernels with the same arguments.
+def _plain(*tensors):
+    """True when every tensor is an ordinary eager tensor (no fake / functional wrapper)."""
+    if torch.compiler.is_compiling():
+        return False
+    for t in tensors:
+        if t is not None and type(t) is not Tensor and type(t) is not torch.nn.Parameter:
+            return False
+    return True
+
+
+_PARAM_CACHE = {}
+
+
+def _cached_params(key):
+    """(params struct, face_rec_bytes, pixel_saved_bytes) per configuration tuple."""
+    hit = _PARAM_CACHE.get(key)
+    if hit is None:
+        p = L.make_params(*key)
+        rec_b, saved_b, _ = L.raster_sizes(p)
+        hit = (p, rec_b, saved_b)
+        if len(_PARAM_CACHE) > 256:
+            _PARAM_CACHE.clear()
+        _PARAM_CACHE[key] = hit
+    return hit
+
+
+def _raster_backward_call(p, g, tex, rec, saved, need_tex, B, F):
+    gfv = torch.empty((B, F, 3, 3), dtype=torch.float32, device=g.device)
+    gtex = torch.empty_like(tex) if (tex is not None and need_tex) else None
+    L.check(L.lib().sv3d_raster_backward(ctypes.byref(p), _ptr(tex), _ptr(rec), _ptr(saved), _ptr(g),
+                                         _ptr(gfv), _ptr(gtex), None, ctypes.c_size_t(0), _stream(g)),
+            "sv3d_raster_backward")
+    return gfv, gtex
+
+
+class _RenderFn(torch.autograd.Function):
+    """`render_op` / `soft_rasterize_op` without the dispatcher: mesh given -> sv3d_render_forward,
+    else face_vertices -> sv3d_raster_forward."""
+
+    @staticmethod
+    def forward(ctx, geom, cams, faces, textures, mesh_args, key):
+        # geom: vertices [B,V,3] when cams is given, else face_vertices [B,F,3,3]
+        x = _f32c(geom)
+        tex = _f32c(textures) if key[4] != L.SV3D_TEX_NONE else None
+        p, rec_b, saved_b = _cached_params(key)
+        B, S, aa = key[0], key[2], key[3]
+        dev = x.device
+        with torch.cuda.device(dev):
+            rgba = torch.empty((B, 4, S // aa, S // aa), dtype=torch.float32, device=dev)
+            rec = torch.empty(rec_b // 4, dtype=torch.float32, device=dev)
+            saved = torch.empty(saved_b // 4, dtype=torch.float32, device=dev)
+            if cams is not None:
+                c = _f32c(cams)
+                m = L.make_mesh_input(x, c, faces, *mesh_args)
+                L.check(L.lib().sv3d_render_forward(ctypes.byref(p), ctypes.byref(m), _ptr(tex), None,
+                                                    _ptr(rgba), _ptr(rec), _ptr(saved), _stream(x)),
+                        "sv3d_render_forward")
+                ctx.save_for_backward(x, c, faces, rec, saved, tex)
+            else:
+                L.check(L.lib().sv3d_raster_forward(ctypes.byref(p), _ptr(x), _ptr(tex), _ptr(rgba), _ptr(rec),
+                                                    _ptr(saved), _stream(x)), "sv3d_raster_forward")
+                ctx.save_for_backward(rec, saved, tex)
+        ctx.key, ctx.mesh_args, ctx.has_mesh = key, mesh_args, cams is not None
+        ctx.dtypes = (geom.dtype, cams.dtype if cams is not None else None,
+                      textures.dtype if textures is not None else None)
+        return rgba
+
+    @staticmethod
+    def backward(ctx, grad_rgba):
+        key = ctx.key
+        p, _, _ = _cached_params(key)
+        g = _f32c(grad_rgba)
+        need_tex = ctx.needs_input_grad[3]
+        with torch.cuda.device(g.device):
+            if ctx.has_mesh:
+                x, c, faces, rec, saved, tex = ctx.saved_tensors
+                gfv, gtex = _raster_backward_call(p, g, tex, rec, saved, need_tex, key[0], key[1])
+                gv, gc = torch.empty_like(x), torch.empty_like(c)
+                m = L.make_mesh_input(x, c, faces, ctx.mesh_args[0], ctx.mesh_args[1], (0.0, 0.0, 0.0))
+                L.check(L.lib().sv3d_project_scatter(ctypes.byref(m), key[0], key[1], _ptr(gfv), _ptr(gv),
+                                                     _ptr(gc), _stream(g)), "sv3d_project_scatter")
+                ggeom, gcams = gv.to(ctx.dtypes[0]), gc.to(ctx.dtypes[1])
+            else:
+                rec, saved, tex = ctx.saved_tensors
+                gfv, gtex = _raster_backward_call(p, g, tex, rec, saved, need_tex, key[0], key[1])
+                ggeom, gcams = gfv.to(ctx.dtypes[0]), None
+        return ggeom, gcams, None, (gtex.to(ctx.dtypes[2]) if gtex is not None else None), None, None
+
+
+class _ChamferFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, xyz1, xyz2):
+        _check_clouds(xyz1, xyz2)
+        a, b = _f32c(xyz1), _f32c(xyz2)
+        B, N, M = a.shape[0], a.shape[1], b.shape[1]
+        with torch.cuda.device(a.device):
+            d1 = torch.empty((B, N), dtype=torch.float32, device=a.device)
+            d2 = torch.empty((B, M), dtype=torch.float32, device=a.device)
+            i1 = torch.empty((B, N), dtype=torch.int32, device=a.device)
+            i2 = torch.empty((B, M), dtype=torch.int32, device=a.device)
+            L.check(L.lib().sv3d_chamfer_forward(_ptr(a), _ptr(b), B, N, M, _ptr(d1), _ptr(d2), _ptr(i1),
+                                                 _ptr(i2), _stream(a)), "sv3d_chamfer_forward")
+        ctx.save_for_backward(a, b, i1, i2)
+        ctx.dtypes = (xyz1.dtype, xyz2.dtype)
+        ctx.mark_non_differentiable(i1, i2)
+        return d1, d2, i1, i2
+
+    @staticmethod
+    def backward(ctx, gd1, gd2, gi1, gi2):
+        a, b, i1, i2 = ctx.saved_tensors
+        need1, need2 = ctx.needs_input_grad
+        if not (need1 or need2):
+            return None, None
+        B, N, M = a.shape[0], a.shape[1], b.shape[1]
+        gd1 = _f32c(gd1) if gd1 is not None else None
+        gd2 = _f32c(gd2) if gd2 is not None else None
+        with torch.cuda.device(a.device):
+            g1 = torch.empty_like(a) if need1 else None
+            g2 = torch.empty_like(b) if need2 else None
+            L.check(L.lib().sv3d_chamfer_backward(_ptr(a), _ptr(b), B, N, M, _ptr(gd1), _ptr(gd2), _ptr(i1),
+                                                  _ptr(i2), _ptr(g1), _ptr(g2), _stream(a)),
+                    "sv3d_chamfer_backward")
+        return (g1.to(ctx.dtypes[0]) if need1 else None, g2.to(ctx.dtypes[1]) if need2 else None)
