@@ -217,10 +217,20 @@ def rasterize_image(fv, tex, S, **kw):
             diag = (1.0 - wcd[..., 2]) * R - wx - wy
             lower = diag <= 1
             tid = torch.where(lower, wy * R + wx, (R - 1 - wy) * R + (R - 1 - wx))
-            free = (wd > tol) & (wd < 1 - tol)                  # coordinate not pinned by the clamp
-            near_edge = (((fx - fx.round()).abs() < tol * R) & free[..., 0]) | \
-                        (((fy - fy.round()).abs() < tol * R) & free[..., 1]) | \
-                        (((diag - 1).abs() < tol * R) & free[..., 2])
+            # fp32 barycentrics of a face carry rounding of the order eps * |e|^2 / |det| (the edge
+            # functions cancel against a small determinant on edge-on faces), so the band around a
+            # texel-cell boundary inside which the pick is undecidable in single precision scales
+            # with that conditioning number
+            with torch.no_grad():
+                e = torch.stack([px[:, (k + 1) % 3] - px[:, k] for k in range(3)], -1) ** 2 + \
+                    torch.stack([py[:, (k + 1) % 3] - py[:, k] for k in range(3)], -1) ** 2
+                det = ((px[:, 1] - px[:, 0]) * (py[:, 2] - py[:, 0]) -
+                       (py[:, 1] - py[:, 0]) * (px[:, 2] - px[:, 0])).abs().clamp(min=1e-10)
+                tolf = (tol * (e.max(-1).values / det).clamp(min=1.0))[None]     # [1,F]
+            free = (wd > tolf[..., None]) & (wd < 1 - tolf[..., None])   # coordinate not pinned by the clamp
+            near_edge = (((fx - fx.round()).abs() < tolf * R) & free[..., 0]) | \
+                        (((fy - fy.round()).abs() < tolf * R) & free[..., 1]) | \
+                        (((diag - 1).abs() < tolf * R) & free[..., 2])
             unstable = unstable | (near_edge & contrib & (D.detach() > 1e-7)).any(-1)
             fidx = torch.arange(F)[None].expand(npx, F)
             col = tex[fidx, tid]                                # [P,F,3]

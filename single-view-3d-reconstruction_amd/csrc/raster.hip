@@ -129,12 +129,33 @@ struct PairGeom {
     float D, omD;                 // sigmoid fragment and 1 - D
 };
 
-__device__ inline PairGeom pair_geom(const FaceRec &r, float xp, float yp, const DevParams &P)
+// A pixel centre as the kernels carry it.  (2c + 1 - S) / S is exact in fp32 when S is a power of
+// two; for other sizes x, y hold the rounded value and xl, yl the remainder (about 3e-8), which
+// the LO variants subtract as well: without it the rounding moves every pixel by that much against
+// the faces, and the 1/sigma slope of the fragments turns it into 1e-5 .. 1e-4 of relative error.
+struct Pixel {
+    float x, y, xl, yl;
+};
+
+template <bool LO>
+__device__ inline Pixel make_pixel(float kx, float ky, float xp, float yp, float fS, float inv_S)
+{
+    // kx, ky: the integers 2c + 1 - S; xp, yp: their fp32 quotients by S (any rounding)
+    Pixel q;
+    q.x = xp; q.y = yp;
+    q.xl = LO ? fmaf(-xp, fS, kx) * inv_S : 0.f;
+    q.yl = LO ? fmaf(-yp, fS, ky) * inv_S : 0.f;
+    return q;
+}
+
+template <bool LO>
+__device__ inline PairGeom pair_geom(const FaceRec &r, const Pixel &px, const DevParams &P)
 {
     PairGeom g;
-    const float a0x = r.p0x - xp, a0y = r.p0y - yp;
-    const float a1x = r.p1x - xp, a1y = r.p1y - yp;
-    const float a2x = r.p2x - xp, a2y = r.p2y - yp;
+    const float xp = px.x, yp = px.y;
+    const float a0x = LO ? (r.p0x - xp) - px.xl : r.p0x - xp, a0y = LO ? (r.p0y - yp) - px.yl : r.p0y - yp;
+    const float a1x = LO ? (r.p1x - xp) - px.xl : r.p1x - xp, a1y = LO ? (r.p1y - yp) - px.yl : r.p1y - yp;
+    const float a2x = LO ? (r.p2x - xp) - px.xl : r.p2x - xp, a2y = LO ? (r.p2y - yp) - px.yl : r.p2y - yp;
     const float t0 = sat(-(a0x * r.e0x + a0y * r.e0y) * r.il0);
     const float t1 = sat(-(a1x * r.e1x + a1y * r.e1y) * r.il1);
     const float t2 = sat(-(a2x * r.e2x + a2y * r.e2y) * r.il2);
@@ -175,11 +196,13 @@ __device__ inline PairGeom pair_geom(const FaceRec &r, float xp, float yp, const
 // outside pixel at or beyond the cull distance exp(x) <= dist_eps/(1-dist_eps) = 1e-10 is absorbed
 // by the 1 + ..., so the value is exactly 1 there -- the same as skipping the pair -- without
 // testing for it.  (Only taken when dist_eps is below half an fp32 ulp of 1: DevParams::alpha_fast.)
-__device__ inline float pair_one_minus_D(const FaceRec &r, float xp, float yp, const DevParams &P)
+template <bool LO>
+__device__ inline float pair_one_minus_D(const FaceRec &r, const Pixel &px, const DevParams &P)
 {
-    const float a0x = r.p0x - xp, a0y = r.p0y - yp;
-    const float a1x = r.p1x - xp, a1y = r.p1y - yp;
-    const float a2x = r.p2x - xp, a2y = r.p2y - yp;
+    const float xp = px.x, yp = px.y;
+    const float a0x = LO ? (r.p0x - xp) - px.xl : r.p0x - xp, a0y = LO ? (r.p0y - yp) - px.yl : r.p0y - yp;
+    const float a1x = LO ? (r.p1x - xp) - px.xl : r.p1x - xp, a1y = LO ? (r.p1y - yp) - px.yl : r.p1y - yp;
+    const float a2x = LO ? (r.p2x - xp) - px.xl : r.p2x - xp, a2y = LO ? (r.p2y - yp) - px.yl : r.p2y - yp;
     const float t0 = sat(-(a0x * r.e0x + a0y * r.e0y) * r.il0);
     const float t1 = sat(-(a1x * r.e1x + a1y * r.e1y) * r.il1);
     const float t2 = sat(-(a2x * r.e2x + a2y * r.e2y) * r.il2);
@@ -380,7 +403,7 @@ __device__ inline int wave_inclusive_scan(int v)
 // per block, which take alternate hits of the block's face list and merge their partial pixel
 // states through LDS at the end -- the kernel's span at small batches is its longest single wave
 // (a silhouette-ring block with ~60 faces), and this halves it.
-template <int MODE, int SPLIT>
+template <int MODE, int SPLIT, bool LO>
 __global__ __launch_bounds__(kThreads * SPLIT) void raster_forward_kernel(
     DevParams P, const float4 *__restrict__ rec, const uint2 *__restrict__ pbox,
     const float *__restrict__ tex, float *__restrict__ rgba, float *__restrict__ saved)
@@ -416,6 +439,8 @@ __global__ __launch_bounds__(kThreads * SPLIT) void raster_forward_kernel(
     const int row = blk_r0 + (quad >> 2) * 2 + (sub >> 1);
     float xp, yp;
     pixel_centre(col, row, S, P.inv_S, xp, yp);
+    const Pixel px = make_pixel<LO>((float)(2 * col + 1 - S), (float)(2 * (S - 1 - row) + 1 - S), xp, yp,
+                                    (float)S, P.inv_S);
     // NDC extent of the pixel centres of this wave's block
     float bxa, bxb, bya, byb;
     pixel_centre(blk_c0, blk_r0 + 7, S, P.inv_S, bxa, bya);
@@ -481,13 +506,13 @@ __global__ __launch_bounds__(kThreads * SPLIT) void raster_forward_kernel(
                 mask &= mask - 1;
                 const FaceRec r = load_rec(&s_rec[jj * kRecPad4]);
                 if (MODE == SV3D_TEX_NONE && P.alpha_fast) {
-                    A *= pair_one_minus_D(r, xp, yp, P);
+                    A *= pair_one_minus_D<LO>(r, px, P);
 #ifdef SV3D_TRACE
                     ++trace_visits;
 #endif
                     continue;
                 }
-                const PairGeom g = pair_geom(r, xp, yp, P);
+                const PairGeom g = pair_geom<LO>(r, px, P);
                 A *= g.omD;
 #ifdef SV3D_TRACE
                 ++trace_visits;
@@ -716,7 +741,7 @@ __device__ inline float wave_sum_lane63(float v)
 // `saved` are the forward's per-raster-pixel aggregates (1 float in silhouette mode, 6 in the
 // colour modes) and `grad_rgba` the incoming gradient at output resolution; both are folded per
 // visit, so there is no per-pixel preparation pass and no scratch buffer.
-template <int MODE>
+template <int MODE, bool LO>
 __global__ __launch_bounds__(kThreads) void raster_backward_kernel(
     DevParams P, const float4 *__restrict__ rec, const uint2 *__restrict__ pbox,
     const float *__restrict__ tex, const float *__restrict__ saved, const float *__restrict__ grad_rgba,
@@ -791,8 +816,10 @@ __global__ __launch_bounds__(kThreads) void raster_backward_kernel(
 
     // Raw per-pixel inputs: the forward's saved aggregates and the incoming gradient.  They are
     // combined where they are used, so that the loads stay in flight across a step.
+    // integers 2c + 1 - S of the box's first column and row (exact in fp32)
+    const float kx0 = (float)(2 * col0 + 1 - S), ky0 = (float)(2 * (S - 1 - row0) + 1 - S), fS = (float)S;
     struct PixIn {
-        float xp, yp;
+        float xp, yp, xl, yl;
         float A, ssum, m, cr, cg, cb;       // saved: 1 - alpha product, softmax sum, max, RGB
         float ga, g0, g1, g2;               // dL/d(alpha, R, G, B) of the output pixel
         bool valid;
@@ -805,6 +832,12 @@ __global__ __launch_bounds__(kThreads) void raster_backward_kernel(
         const float cx = in.valid ? rx_f : 0.f, cy = in.valid ? ry_f : 0.f;
         in.xp = fmaf(cx, step, xp0);
         in.yp = fmaf(-cy, step, yp0);
+        if (LO) {           // remainder of the exact centre over the rounded one, see struct Pixel
+            in.xl = fmaf(-in.xp, fS, fmaf(2.f, cx, kx0)) * P.inv_S;
+            in.yl = fmaf(-in.yp, fS, fmaf(-2.f, cy, ky0)) * P.inv_S;
+        } else {
+            in.xl = in.yl = 0.f;
+        }
         const unsigned prow = (unsigned)(row0 + (int)cy), pcol = (unsigned)(col0 + (int)cx);
         const unsigned pix = prow * (unsigned)S + pcol;
         const unsigned gpix = P.aa == 2 ? (prow >> 1) * (unsigned)H + (pcol >> 1) : pix;
@@ -844,7 +877,9 @@ __global__ __launch_bounds__(kThreads) void raster_backward_kernel(
             G0 = in.g0 * is; G1 = in.g1 * is; G2 = in.g2 * is;
         }
 
-        PairGeom g = pair_geom(r, xp, yp, P);
+        Pixel px;
+        px.x = xp; px.y = yp; px.xl = in.xl; px.yl = in.yl;
+        PairGeom g = pair_geom<LO>(r, px, P);
         const bool act = valid && g.act;
         float gx = act ? P0 * g.D : 0.f;        // dL/dx, x = +-d2/sigma, through alpha
 
@@ -1063,23 +1098,27 @@ int raster_forward_impl(const sv3d_raster_params *p, const float *face_vertices,
                            d, face_vertices, rec, pbox);
     }
     const int tiles = (d.S + kTile - 1) / kTile;
-    dim3 grid((unsigned)tiles * tiles * d.B), block(kThreads);
+    dim3 grid((unsigned)tiles * tiles * d.B);
     float *saved = static_cast<float *>(pixel_saved);
     if (ev_start) (void)hipEventRecord(ev_start, s);
-    // two waves per block while the grid is small enough that single waves set the kernel's span
+    // two waves per block while the grid is small enough that single waves set the kernel's span;
+    // the remainder-carrying variants when S is not a power of two
     const bool split = (long)tiles * tiles * d.B <= 4096;
-#define SV3D_LAUNCH_FWD(M)                                                                               \
-    do {                                                                                                 \
-        if (split)                                                                                       \
-            hipLaunchKernelGGL((raster_forward_kernel<M, 2>), grid, dim3(2 * kThreads), 0, s, d, rec, pbox, \
-                               textures, rgba_out, saved);                                               \
-        else                                                                                             \
-            hipLaunchKernelGGL((raster_forward_kernel<M, 1>), grid, block, 0, s, d, rec, pbox, textures, \
-                               rgba_out, saved);                                                         \
+    const bool lo = (d.S & (d.S - 1)) != 0;
+#define SV3D_LAUNCH_FWD2(M, SP, LO_)                                                                   \
+    hipLaunchKernelGGL((raster_forward_kernel<M, SP, LO_>), grid, dim3(SP * kThreads), 0, s, d, rec, pbox, \
+                       textures, rgba_out, saved)
+#define SV3D_LAUNCH_FWD(M)                                                                             \
+    do {                                                                                               \
+        if (split && lo) SV3D_LAUNCH_FWD2(M, 2, true);                                                 \
+        else if (split) SV3D_LAUNCH_FWD2(M, 2, false);                                                 \
+        else if (lo) SV3D_LAUNCH_FWD2(M, 1, true);                                                     \
+        else SV3D_LAUNCH_FWD2(M, 1, false);                                                            \
     } while (0)
     if (d.mode == SV3D_TEX_NONE) SV3D_LAUNCH_FWD(SV3D_TEX_NONE);
     else if (d.mode == SV3D_TEX_SURFACE) SV3D_LAUNCH_FWD(SV3D_TEX_SURFACE);
     else SV3D_LAUNCH_FWD(SV3D_TEX_VERTEX);
+#undef SV3D_LAUNCH_FWD2
 #undef SV3D_LAUNCH_FWD
     if (ev_stop) (void)hipEventRecord(ev_stop, s);
     return launch_status();
@@ -1102,17 +1141,22 @@ int raster_backward_impl(const sv3d_raster_params *p, const float *textures, con
     const float *saved = static_cast<const float *>(pixel_saved);
     const dim3 fgrid((d.B * d.F + 3) / 4), block(kThreads);
     if (ev_start) (void)hipEventRecord(ev_start, s);
-    if (d.mode == SV3D_TEX_NONE) {
-        hipLaunchKernelGGL(raster_backward_kernel<SV3D_TEX_NONE>, fgrid, block, 0, s, d, rec, pbox,
-                           textures, saved, grad_rgba, grad_face_vertices, (float *)nullptr);
-    } else if (d.mode == SV3D_TEX_SURFACE) {
-        const size_t lds = (size_t)4 * tex_lds_floats(d.R * d.R) * sizeof(float);
-        hipLaunchKernelGGL(raster_backward_kernel<SV3D_TEX_SURFACE>, fgrid, block, lds, s, d, rec, pbox,
-                           textures, saved, grad_rgba, grad_face_vertices, grad_textures);
-    } else {
-        hipLaunchKernelGGL(raster_backward_kernel<SV3D_TEX_VERTEX>, fgrid, block, 0, s, d, rec, pbox,
-                           textures, saved, grad_rgba, grad_face_vertices, grad_textures);
-    }
+    const bool lo = (d.S & (d.S - 1)) != 0;         // raster size not a power of two: see struct Pixel
+    const size_t lds = d.mode == SV3D_TEX_SURFACE ? (size_t)4 * tex_lds_floats(d.R * d.R) * sizeof(float) : 0;
+    float *gt = d.mode == SV3D_TEX_NONE ? nullptr : grad_textures;
+#define SV3D_LAUNCH_BWD(M)                                                                              \
+    do {                                                                                                \
+        if (lo)                                                                                         \
+            hipLaunchKernelGGL((raster_backward_kernel<M, true>), fgrid, block, lds, s, d, rec, pbox,   \
+                               textures, saved, grad_rgba, grad_face_vertices, gt);                     \
+        else                                                                                            \
+            hipLaunchKernelGGL((raster_backward_kernel<M, false>), fgrid, block, lds, s, d, rec, pbox,  \
+                               textures, saved, grad_rgba, grad_face_vertices, gt);                     \
+    } while (0)
+    if (d.mode == SV3D_TEX_NONE) SV3D_LAUNCH_BWD(SV3D_TEX_NONE);
+    else if (d.mode == SV3D_TEX_SURFACE) SV3D_LAUNCH_BWD(SV3D_TEX_SURFACE);
+    else SV3D_LAUNCH_BWD(SV3D_TEX_VERTEX);
+#undef SV3D_LAUNCH_BWD
     if (ev_stop) (void)hipEventRecord(ev_stop, s);
     return launch_status();
 }

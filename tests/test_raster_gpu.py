@@ -92,7 +92,7 @@ def _fp32_floor(fv, tex, img, aa, mode, grad, unstable, want, wfv, wtex, **kw):
             rel_err(x.grad, wfv), rel_err(t.grad, wtex) if wtex is not None else 0.0)
 
 
-def _compare(name, fv, tex, img, aa, mode, fp32_floor=False, grad_tol=None, **kw):
+def _compare(name, fv, tex, img, aa, mode, fp32_floor=False, grad_tol=None, img_tol=None, **kw):
     B = fv.shape[0]
     grad = 2 * torch.rand(B, 4, img, img, generator=torch.Generator().manual_seed(4)) - 1
     want, wfv, wtex, unstable, nact = _oracle(fv, tex, img, aa, mode, grad, **kw)
@@ -112,7 +112,7 @@ def _compare(name, fv, tex, img, aa, mode, fp32_floor=False, grad_tol=None, **kw
         # from their fp64 evaluation on this input (recorded beside the kernel's own error)
         itol, ftol, ttol = _fp32_floor(fv, tex, img, aa, mode, grad, unstable, want, wfv, wtex, **kw)
         _record(name + "_fp32_oracle_floor", img=itol, grad_fv=ftol, grad_tex=ttol, unstable=frac, active=sum(nact))
-    assert e_img < IMG_TOL, ("image", e_img)
+    assert e_img < (img_tol if img_tol is not None else IMG_TOL), ("image", e_img)
     assert e_fv < gtol, ("grad_face_vertices", e_fv)
     assert e_tex < gtol, ("grad_textures", e_tex)
     assert wfv.abs().max() > 0
@@ -146,13 +146,10 @@ def test_parity_surface_texture_resolutions(R):
     verts, faces = load_mesh(1)
     fv = camera_space_faces(verts, faces, 2, seed=3)
     tex = _textures("surface", 2, faces.shape[0], R)
-    # 80 large faces, several nearly edge-on.  Through such a face the colour path's gradient runs
-    # over 1/det (1e3..1e5) with large terms of both signs per pixel, so the fp32 sum carries noise
-    # of a few 1e-5 of the largest gradient whose value moves with the summation order (measured
-    # 1.2e-5 .. 5.2e-5 across builds); a dense fp32 evaluation of the upstream formulas is off by
-    # 5e-3 on the same input and is recorded beside it.  Bar for this case: 1e-4.
-    _compare("ico1_surface_R%d" % R, fv, tex, 48, False, "surface", fp32_floor=True, grad_tol=1e-4,
-             sigma=1e-4, gamma=1e-3)
+    # raster size 48: not a power of two, so the kernels run their remainder-carrying pixel-centre
+    # variants (without the remainder this case sits at 1e-5 .. 5e-5).  A dense fp32 evaluation of
+    # the upstream formulas is off by ~2e-3 on this input; it is recorded beside the kernels' error.
+    _compare("ico1_surface_R%d" % R, fv, tex, 48, False, "surface", fp32_floor=True, sigma=1e-4, gamma=1e-3)
 
 
 def test_parity_wide_softmax_and_single_sided():
@@ -380,3 +377,33 @@ def test_degenerate_faces_match_oracle_and_stay_finite(mode):
     out.sum().backward()
     assert torch.isfinite(out).all() and torch.isfinite(x.grad).all()
     assert t is None or torch.isfinite(t.grad).all()
+
+
+SWEEP_GRAD_TOL = 2e-5
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_parity_seeded_random_configurations(seed):
+    """Seeded sweep over raster size (powers of two and not), anti-aliasing, mode, sigma, gamma,
+    texture resolution, batch, sidedness and mesh against the oracle (fixed seeds: the sweep is
+    deterministic).  Images hold the 1e-5 bar; gradients get 2e-5 because the sweep pairs sigma
+    1e-5 with rasters of 16..56 pixels, where one pixel spans several cull margins and a
+    gradient hangs on a handful of fragments whose exponent d^2/sigma reaches 23 (measured
+    worst 1.3e-5; every case at sigma >= 3e-5 stays below 1e-5)."""
+    g = torch.Generator().manual_seed(1000 + seed)
+    pick = lambda xs: xs[int(torch.randint(len(xs), (1,), generator=g))]
+    sub = pick([1, 1, 2])
+    img = pick([16, 24, 40, 56])
+    aa = bool(seed & 1)
+    mode = pick(["none", "surface", "vertex"])
+    sigma = pick([1e-4, 3e-5, 1e-5])
+    gamma = pick([1e-1, 1e-2, 1e-3])
+    R = pick([1, 2, 5])
+    B = pick([1, 2, 3])
+    double_side = pick([True, True, False])
+    bgc = tuple(float(x) for x in torch.rand(3, generator=g))
+    verts, faces = load_mesh(sub)
+    fv = camera_space_faces(verts, faces, B, seed=50 + seed)
+    tex = _textures(mode, B, faces.shape[0], R, seed=seed)
+    _compare("sweep_%d_%s_S%d_aa%d" % (seed, mode, img, aa), fv, tex, img, aa, mode, grad_tol=SWEEP_GRAD_TOL,
+             sigma=sigma, gamma=gamma, double_side=double_side, background=bgc)
