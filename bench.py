@@ -99,6 +99,9 @@ def build_inputs(args, device, seed):
         tex = torch.rand(B, faces.shape[0], args.tex_size ** 2, 3, generator=g).to(device)
     elif args.mode == "vertex":
         tex = torch.rand(B, faces.shape[0], 3, 3, generator=g).to(device)
+    elif args.mode == "vertex8":
+        tex = torch.rand(B, faces.shape[0], 3, 8, generator=g).to(device)
+        grad = (2 * torch.rand(B, 9, H, H, generator=g) - 1).to(device)
     return fv.contiguous(), tex, grad.contiguous()
 
 

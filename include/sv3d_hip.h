@@ -34,7 +34,12 @@ typedef enum sv3d_status {
     SV3D_ERR_LAUNCH = -4         /* hipGetLastError() != hipSuccess after a launch */
 } sv3d_status;
 
-enum { SV3D_TEX_NONE = 0, SV3D_TEX_SURFACE = 1, SV3D_TEX_VERTEX = 2 };
+/* SV3D_TEX_VERTEX8: eight scalar per-corner channels rendered in one pass (the reference renders
+ * its part maps one at a time, each copied into three colour channels of which one is kept,
+ * main.py:422-426; channel c of this mode equals channel 0 of such a render of map c).
+ * textures [B,F,3,8], rgba_out / grad_rgba [B,9,S/aa,S/aa] (eight channels, then alpha), every
+ * channel's background is background[0].                                                   */
+enum { SV3D_TEX_NONE = 0, SV3D_TEX_SURFACE = 1, SV3D_TEX_VERTEX = 2, SV3D_TEX_VERTEX8 = 3 };
 
 /* Rasterizer configuration: the arguments sr.SoftRenderer(...) receives at
  * nnutils/softras.py:33-37 plus the SoftRas defaults it leaves untouched. */
@@ -72,8 +77,10 @@ int sv3d_raster_sizes(const sv3d_raster_params *p, size_t *face_rec_bytes,
 /* Replaces soft_renderer's `soft_rasterize` forward as reached from
  * nnutils/softras.py:64,75,77 (sr.SoftRenderer.__call__ / .rasterizer).
  *   face_vertices [B,F,3,3]  (x, y, z) of the three corners, camera space, y up
- *   textures      NONE: ignored (may be NULL); SURFACE [B,F,R*R,3]; VERTEX [B,F,3,3]
+ *   textures      NONE: ignored (may be NULL); SURFACE [B,F,R*R,3]; VERTEX [B,F,3,3];
+ *                 VERTEX8 [B,F,3,8]
  *   rgba_out      [B,4,S/aa,S/aa]   channels R,G,B,alpha, row 0 = top of the image
+ *                 (VERTEX8: [B,9,S/aa,S/aa])
  *   face_rec, pixel_saved: see sv3d_raster_sizes                                   */
 int sv3d_raster_forward(const sv3d_raster_params *p, const float *face_vertices,
                         const float *textures, float *rgba_out, void *face_rec,
@@ -140,6 +147,17 @@ int sv3d_face_gather(const float *values, const int32_t *faces, int32_t B, int32
  * index to prepare, bitwise repeatable.  grad_values [B,V,3] is fully overwritten.   */
 int sv3d_face_scatter(const float *grad_out, const int32_t *faces, int32_t B, int32_t V, int32_t F,
                       int32_t faces_batch, const float *scale, float *grad_values, void *stream);
+
+/* `vertices[faces]`-style gather of C <= 8 scalar channels per vertex and its backward, for the
+ * per-vertex part maps of main.py:422-426 rendered with SV3D_TEX_VERTEX8:
+ *   out[b,f,k,:] = values[b, faces[fb,f,k], :]         values [B,V,C] -> out [B,F,3,C]
+ *   grad_values[b,v,:] = sum of grad_out[b,f,k,:] over corners (f,k) with faces[fb,f,k] == v,
+ *   in ascending (f,k) order (no atomics); meshes whose sort tables exceed the LDS
+ *   (2V + 3F ints > 150 KB) return SV3D_ERR_UNSUPPORTED.                                   */
+int sv3d_face_gather_n(const float *values, const int32_t *faces, int32_t B, int32_t V, int32_t F,
+                       int32_t faces_batch, int32_t C, float *out, void *stream);
+int sv3d_face_scatter_n(const float *grad_out, const int32_t *faces, int32_t B, int32_t V, int32_t F,
+                        int32_t faces_batch, int32_t C, float *grad_values, void *stream);
 
 /* The renderer call's input stage, nnutils/softras.py:58-61: the weak-perspective camera
  * `orthographic_proj_withz` (nnutils/geom_utils.py:63-80, quat_rotate :143-161) followed by

@@ -179,6 +179,10 @@ def rasterize_image(fv, tex, S, **kw):
     alpha = 1.0 - torch.prod(1.0 - D, dim=1)                    # [P]
 
     bg = torch.tensor(P["background"], dtype=dt)
+    if mode == "vertex8":
+        # eight scalar per-corner channels in one pass; channel c is channel 0 of the reference's
+        # render of part map c (main.py:422-426), so every channel takes background[0]
+        bg = bg[:1].repeat(tex.shape[2])
     if mode == "none":
         rgb = bg[:, None].expand(3, npx).clone()
         aggr = torch.zeros(2, npx, dtype=dt)
@@ -244,7 +248,7 @@ def rasterize_image(fv, tex, S, **kw):
 
     rgba = torch.cat([rgb, alpha[None]], 0)
     if P["pixels"] is None:
-        rgba, aggr, unstable = rgba.reshape(4, S, S), aggr.reshape(2, S, S), unstable.reshape(S, S)
+        rgba, aggr, unstable = rgba.reshape(-1, S, S), aggr.reshape(2, S, S), unstable.reshape(S, S)
     return dict(rgba=rgba, aggr=aggr, n_active=n_active, unstable=unstable)
 
 

@@ -155,28 +155,12 @@ __device__ inline void block_sum7(float acc[7], float (*s_red)[8], float *dst)
     }
 }
 
-// Backward of the gather (and, with PROJECT, of the camera in front of it): one 1024-thread
-// block per image groups the image's 3F corner slots by vertex with an LDS counting sort, then
-// one thread per vertex adds its slots' gradients in ascending slot order.  The sort places
-// slots with LDS integer atomics, so the order inside a bucket varies; picking the next larger
-// slot id on every step makes the float sum order -- and the result bits -- fixed.  No float
-// atomics, no index kept between calls.  Dynamic LDS: (2V + 3F) ints.
-template <bool PROJECT>
-__global__ __launch_bounds__(kSortThreads) void mesh_scatter_kernel(
-    const float *__restrict__ grad_out, const int32_t *__restrict__ faces, int B, int V, int F,
-    int faces_batch, Affine a, const float *__restrict__ vertices, const float *__restrict__ cams,
-    float offset_z, float *__restrict__ grad_values, float *__restrict__ grad_cams)
+// LDS counting sort of an image's 3F corner slots by vertex: on return bucket[start[v] .. fill[v])
+// holds the slots that reference vertex v, in arbitrary order.  All kSortThreads threads call it.
+__device__ inline void build_buckets(const int32_t *__restrict__ fb, int V, int nslots, int *fill,
+                                     int *start, int *bucket, int *s_wave)
 {
-    extern __shared__ int smem[];
-    __shared__ int s_wave[kSortThreads / 64];
-    __shared__ float s_red[kSortThreads / 64][8];
-    int *fill = smem;                 // per vertex: slot count, then running fill pointer
-    int *start = smem + V;            // per vertex: first entry of its bucket
-    int *bucket = smem + 2 * V;       // slot ids grouped by vertex
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int nslots = F * 3;
-    const int32_t *fb = faces + (faces_batch > 1 ? (long)b * nslots : 0);
-
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int v = tid; v < V; v += kSortThreads) fill[v] = 0;
     __syncthreads();
     for (int i = tid; i < nslots; i += kSortThreads) atomicAdd(&fill[min(max(fb[i], 0), V - 1)], 1);
@@ -205,6 +189,43 @@ __global__ __launch_bounds__(kSortThreads) void mesh_scatter_kernel(
     __syncthreads();
     for (int i = tid; i < nslots; i += kSortThreads) bucket[atomicAdd(&fill[min(max(fb[i], 0), V - 1)], 1)] = i;
     __syncthreads();
+}
+
+// Next slot of bucket [s0, s1) above `last`, so that a bucket is walked in ascending slot order
+// whatever order the sort left it in.
+__device__ inline int next_slot(const int *bucket, int s0, int s1, int last)
+{
+    int m = INT_MAX;
+    for (int j = s0; j < s1; ++j) {
+        const int s = bucket[j];
+        m = (s > last && s < m) ? s : m;
+    }
+    return m;
+}
+
+// Backward of the gather (and, with PROJECT, of the camera in front of it): one 1024-thread
+// block per image groups the image's 3F corner slots by vertex with an LDS counting sort, then
+// one thread per vertex adds its slots' gradients in ascending slot order.  The sort places
+// slots with LDS integer atomics, so the order inside a bucket varies; picking the next larger
+// slot id on every step makes the float sum order -- and the result bits -- fixed.  No float
+// atomics, no index kept between calls.  Dynamic LDS: (2V + 3F) ints.
+template <bool PROJECT>
+__global__ __launch_bounds__(kSortThreads) void mesh_scatter_kernel(
+    const float *__restrict__ grad_out, const int32_t *__restrict__ faces, int B, int V, int F,
+    int faces_batch, Affine a, const float *__restrict__ vertices, const float *__restrict__ cams,
+    float offset_z, float *__restrict__ grad_values, float *__restrict__ grad_cams)
+{
+    extern __shared__ int smem[];
+    __shared__ int s_wave[kSortThreads / 64];
+    __shared__ float s_red[kSortThreads / 64][8];
+    int *fill = smem;                 // per vertex: slot count, then running fill pointer
+    int *start = smem + V;            // per vertex: first entry of its bucket
+    int *bucket = smem + 2 * V;       // slot ids grouped by vertex
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int nslots = F * 3;
+    const int32_t *fb = faces + (faces_batch > 1 ? (long)b * nslots : 0);
+
+    build_buckets(fb, V, nslots, fill, start, bucket, s_wave);
 
     Camera c;
     if (PROJECT) c = sv3d_dev::load_camera(cams + (long)b * 7, offset_z);
@@ -215,14 +236,9 @@ __global__ __launch_bounds__(kSortThreads) void mesh_scatter_kernel(
         float x = 0.f, y = 0.f, z = 0.f;
         int last = -1;
         for (int i = s0; i < s1; ++i) {
-            int m = INT_MAX;
-            for (int j = s0; j < s1; ++j) {
-                const int s = bucket[j];
-                m = (s > last && s < m) ? s : m;
-            }
-            const float *gs = g + 3 * (long)m;
+            last = next_slot(bucket, s0, s1, last);
+            const float *gs = g + 3 * (long)last;
             x += gs[0]; y += gs[1]; z += gs[2];
-            last = m;
         }
         x *= a.s0; y *= a.s1; z *= a.s2;
         float *dst = grad_values + ((long)b * V + v) * 3;
@@ -280,6 +296,51 @@ bool launch_sorted_scatter(const float *grad_out, const int32_t *faces, int B, i
     hipLaunchKernelGGL(mesh_scatter_kernel<PROJECT>, dim3(B), dim3(kSortThreads), lds, s, grad_out, faces,
                        B, V, F, faces_batch, a, vertices, cams, offset_z, grad_values, grad_cams);
     return true;
+}
+
+// Gather / scatter of C <= 8 scalar channels per vertex (part maps): out[b,f,k,:] = values[b, faces[fb,f,k], :].
+__global__ __launch_bounds__(kThreads) void face_gather_n_kernel(
+    const float *__restrict__ values, const int32_t *__restrict__ faces, int B, int V, int F,
+    int faces_batch, int C, float *__restrict__ out)
+{
+    const long gid = (long)blockIdx.x * kThreads + threadIdx.x;
+    const long per = (long)F * 3;
+    if (gid >= (long)B * per) return;
+    const int b = (int)(gid / per);
+    const int32_t *fb = faces + (faces_batch > 1 ? (long)b * per : 0);
+    const int v = min(max(fb[gid - (long)b * per], 0), V - 1);
+    const float *src = values + ((long)b * V + v) * C;
+    float *dst = out + gid * C;
+    for (int c = 0; c < C; ++c) dst[c] = src[c];
+}
+
+__global__ __launch_bounds__(kSortThreads) void mesh_scatter_n_kernel(
+    const float *__restrict__ grad_out, const int32_t *__restrict__ faces, int B, int V, int F,
+    int faces_batch, int C, float *__restrict__ grad_values)
+{
+    extern __shared__ int smem[];
+    __shared__ int s_wave[kSortThreads / 64];
+    int *fill = smem, *start = smem + V, *bucket = smem + 2 * V;
+    const int b = blockIdx.x, nslots = F * 3;
+    const int32_t *fb = faces + (faces_batch > 1 ? (long)b * nslots : 0);
+    build_buckets(fb, V, nslots, fill, start, bucket, s_wave);
+    const float *g = grad_out + (long)b * nslots * C;
+    for (int v = threadIdx.x; v < V; v += kSortThreads) {
+        const int s0 = start[v], s1 = fill[v];
+        float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        int last = -1;
+        for (int i = s0; i < s1; ++i) {
+            last = next_slot(bucket, s0, s1, last);
+            const float *gs = g + (long)last * C;
+#pragma unroll
+            for (int c = 0; c < 8; ++c)
+                if (c < C) a[c] += gs[c];
+        }
+        float *dst = grad_values + ((long)b * V + v) * C;
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+            if (c < C) dst[c] = a[c];
+    }
 }
 
 Affine make_affine(const float *scale, const float *shift)
@@ -365,5 +426,40 @@ extern "C" int sv3d_project_scatter(const sv3d_mesh_input *m, int32_t B, int32_t
         hipLaunchKernelGGL(camera_backward_kernel, dim3(B), dim3(kSortThreads), 0, s, V, m->vertices,
                            m->cams, m->offset_z, grad_vertices, grad_cams);
     }
+    return hipGetLastError() == hipSuccess ? SV3D_OK : SV3D_ERR_LAUNCH;
+}
+
+extern "C" int sv3d_face_gather_n(const float *values, const int32_t *faces, int32_t B, int32_t V,
+                                  int32_t F, int32_t faces_batch, int32_t C, float *out, void *stream)
+{
+    if (!values || !faces || !out) return SV3D_ERR_INVALID_ARG;
+    if (B <= 0 || V <= 0 || F <= 0 || C <= 0) return SV3D_ERR_INVALID_ARG;
+    if (faces_batch != 1 && faces_batch != B) return SV3D_ERR_INVALID_ARG;
+    if (C > 8) return SV3D_ERR_UNSUPPORTED;
+    const long n = (long)B * F * 3;
+    if (n > 0x7fffffffL * (long)kThreads / 2) return SV3D_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(face_gather_n_kernel, dim3((unsigned)((n + kThreads - 1) / kThreads)), dim3(kThreads),
+                       0, static_cast<hipStream_t>(stream), values, faces, B, V, F, faces_batch, C, out);
+    return hipGetLastError() == hipSuccess ? SV3D_OK : SV3D_ERR_LAUNCH;
+}
+
+extern "C" int sv3d_face_scatter_n(const float *grad_out, const int32_t *faces, int32_t B, int32_t V,
+                                   int32_t F, int32_t faces_batch, int32_t C, float *grad_values,
+                                   void *stream)
+{
+    if (!grad_out || !faces || !grad_values) return SV3D_ERR_INVALID_ARG;
+    if (B <= 0 || V <= 0 || F <= 0 || C <= 0) return SV3D_ERR_INVALID_ARG;
+    if (faces_batch != 1 && faces_batch != B) return SV3D_ERR_INVALID_ARG;
+    if (C > 8 || B > 65535) return SV3D_ERR_UNSUPPORTED;
+    const size_t lds = sort_lds_bytes(V, F);
+    if (lds > kSortLdsMax) return SV3D_ERR_UNSUPPORTED;
+    if (lds > kSortLdsDefault &&
+        hipFuncSetAttribute(reinterpret_cast<const void *>(&mesh_scatter_n_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+        (void)hipGetLastError();
+        return SV3D_ERR_UNSUPPORTED;
+    }
+    hipLaunchKernelGGL(mesh_scatter_n_kernel, dim3(B), dim3(kSortThreads), lds,
+                       static_cast<hipStream_t>(stream), grad_out, faces, B, V, F, faces_batch, C, grad_values);
     return hipGetLastError() == hipSuccess ? SV3D_OK : SV3D_ERR_LAUNCH;
 }

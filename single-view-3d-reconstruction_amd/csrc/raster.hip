@@ -57,6 +57,10 @@ constexpr int kTile = 16;         // tile side in raster pixels
 constexpr int kListCap = SV3D_LIST_CAP;   // faces staged in LDS at a time (128 B each)
 constexpr int kRecPad4 = kRec4 + 1;       // LDS record stride (144 B): lane-strided reads are conflict free
 
+// Colour channels of a texture mode: RGB, or eight scalar per-corner channels for VERTEX8.
+__host__ __device__ constexpr int mode_channels(int mode) { return mode == SV3D_TEX_VERTEX8 ? 8 : 3; }
+__host__ __device__ constexpr bool mode_vertex(int mode) { return mode == SV3D_TEX_VERTEX || mode == SV3D_TEX_VERTEX8; }
+
 struct DevParams {
     int B, F, S, aa, mode, R, double_side;
     float bg0, bg1, bg2;
@@ -458,7 +462,11 @@ __global__ __launch_bounds__(kThreads * SPLIT) void raster_forward_kernel(
     float A = 1.f;                              // prod (1 - D)
     float m = P.eps - c0shift;                  // running softmax maximum, shifted by c0shift
     float ssum = part == 0 ? P.ssum0 : 0.f;     // the background term enters once, through part 0
-    float C0 = P.bg0 * ssum, C1 = P.bg1 * ssum, C2 = P.bg2 * ssum;
+    constexpr int NC = mode_channels(MODE);     // colour channels
+    float Cc[NC];                               // softmax-weighted colour sums
+#pragma unroll
+    for (int c = 0; c < NC; ++c)                // VERTEX8: every channel is "channel 0" of its own render
+        Cc[c] = (MODE == SV3D_TEX_VERTEX8 ? P.bg0 : (c == 0 ? P.bg0 : (c == 1 ? P.bg1 : P.bg2))) * ssum;
     int hits_seen = 0;                          // hits of this block so far (wave-uniform)
 
     // Conservative per-(block, face) test run lane-parallel over list entries: the block can only
@@ -519,19 +527,21 @@ __global__ __launch_bounds__(kThreads * SPLIT) void raster_forward_kernel(
 #endif
                 if (MODE != SV3D_TEX_NONE) {
                     const PairDepth d = pair_depth(r, g, P);
-                    float k0 = 0.f, k1 = 0.f, k2 = 0.f;
+                    float kc[NC];
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) kc[c] = 0.f;
                     if (d.contrib) {
                         const int fid = s_ids[jj];
                         if (MODE == SV3D_TEX_SURFACE) {
                             const int Ts = P.R * P.R;
                             const float *tp = tex + (((size_t)b * F + fid) * Ts +
                                                      texel_index(d.n0, d.n1, d.n2, P.R)) * 3;
-                            k0 = tp[0]; k1 = tp[1]; k2 = tp[2];
+                            kc[0] = tp[0]; kc[1] = tp[1]; kc[2] = tp[2];
                         } else {
-                            const float *tp = tex + ((size_t)b * F + fid) * 9;
-                            k0 = d.n0 * tp[0] + d.n1 * tp[3] + d.n2 * tp[6];
-                            k1 = d.n0 * tp[1] + d.n1 * tp[4] + d.n2 * tp[7];
-                            k2 = d.n0 * tp[2] + d.n1 * tp[5] + d.n2 * tp[8];
+                            const float *tp = tex + ((size_t)b * F + fid) * (3 * NC);
+#pragma unroll
+                            for (int c = 0; c < NC; ++c)
+                                kc[c] = d.n0 * tp[c] + d.n1 * tp[NC + c] + d.n2 * tp[2 * NC + c];
                         }
                     }
                     const float mnew = d.contrib ? fmaxf(m, d.zn) : m;
@@ -539,9 +549,8 @@ __global__ __launch_bounds__(kThreads * SPLIT) void raster_forward_kernel(
                     const float ez = d.contrib ? ex2((d.zn - mnew) * P.l2e_over_gamma) : 0.f;
                     const float wgt = ez * g.D;
                     ssum = fmaf(rs, ssum, wgt);
-                    C0 = fmaf(rs, C0, wgt * k0);
-                    C1 = fmaf(rs, C1, wgt * k1);
-                    C2 = fmaf(rs, C2, wgt * k2);
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) Cc[c] = fmaf(rs, Cc[c], wgt * kc[c]);
                     m = mnew;
                 }
             }
@@ -603,11 +612,13 @@ __global__ __launch_bounds__(kThreads * SPLIT) void raster_forward_kernel(
 
     if (SPLIT == 2) {
         // merge the two partial pixel states of every block (s_rec is free after the last barrier)
-        float *s_part = reinterpret_cast<float *>(s_rec) + (blk * 64 + lane) * 6;
+        float *s_part = reinterpret_cast<float *>(s_rec) + (blk * 64 + lane) * (3 + NC);
         if (part == 1) {
             s_part[0] = A;
             if (MODE != SV3D_TEX_NONE) {
-                s_part[1] = m; s_part[2] = ssum; s_part[3] = C0; s_part[4] = C1; s_part[5] = C2;
+                s_part[1] = m; s_part[2] = ssum;
+#pragma unroll
+                for (int c = 0; c < NC; ++c) s_part[3 + c] = Cc[c];
             }
         }
         __syncthreads();
@@ -618,56 +629,57 @@ __global__ __launch_bounds__(kThreads * SPLIT) void raster_forward_kernel(
             const float mn = fmaxf(m, m1);
             const float sa = ex2((m - mn) * P.l2e_over_gamma), sb = ex2((m1 - mn) * P.l2e_over_gamma);
             ssum = sa * ssum + sb * s_part[2];
-            C0 = sa * C0 + sb * s_part[3];
-            C1 = sa * C1 + sb * s_part[4];
-            C2 = sa * C2 + sb * s_part[5];
+#pragma unroll
+            for (int c = 0; c < NC; ++c) Cc[c] = sa * Cc[c] + sb * s_part[3 + c];
             m = mn;
         }
     }
 
-    // epilogue
+    // epilogue: o[0..NC-1] colours, o[NC] alpha
     SV3D_STAMP(5);
-    float o0, o1, o2;
+    float o[NC + 1];
     if (MODE != SV3D_TEX_NONE) {
         const float is = 1.f / ssum;
-        o0 = C0 * is; o1 = C1 * is; o2 = C2 * is;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) o[c] = Cc[c] * is;
     } else {
-        o0 = P.bg0; o1 = P.bg1; o2 = P.bg2;
+        o[0] = P.bg0; o[1] = P.bg1; o[2] = P.bg2;
     }
     A = fminf(A, 1.f);                          // e*rcp(1+e) may round a hair above 1
-    float o3 = 1.f - A;
+    o[NC] = 1.f - A;
     const bool inimg = col < S && row < S;
     if (inimg) {
         const size_t pix = ((size_t)b * S + row) * S + col;
         if (MODE == SV3D_TEX_NONE) {
             saved[pix] = A;
-        } else {
+        } else if (NC == 3) {
             float2 *sp = (float2 *)(saved + pix * 6);
             sp[0] = make_float2(A, ssum);
-            sp[1] = make_float2(m, o0);
-            sp[2] = make_float2(o1, o2);
+            sp[1] = make_float2(m, o[0]);
+            sp[2] = make_float2(o[1], o[2]);
+        } else {                                // 12 floats: A, sum, max, eight colours, pad
+            float4 *sp = (float4 *)(saved + pix * 12);
+            sp[0] = make_float4(A, ssum, m, o[0]);
+            sp[1] = make_float4(o[1], o[2], o[3], o[4]);
+            sp[2] = make_float4(o[5], o[6], o[7], 0.f);
         }
     }
     if (P.aa == 2) {
-        if (!inimg) { o0 = o1 = o2 = o3 = 0.f; }
-        o0 += __shfl_xor(o0, 1); o1 += __shfl_xor(o1, 1); o2 += __shfl_xor(o2, 1); o3 += __shfl_xor(o3, 1);
-        o0 += __shfl_xor(o0, 2); o1 += __shfl_xor(o1, 2); o2 += __shfl_xor(o2, 2); o3 += __shfl_xor(o3, 2);
         const int H = S >> 1;
-        if (sub == 0 && inimg) {
-            const size_t o = ((size_t)b * 4 * H + (row >> 1)) * H + (col >> 1);
-            const size_t plane = (size_t)H * H;
-            rgba[o] = 0.25f * o0;
-            rgba[o + plane] = 0.25f * o1;
-            rgba[o + 2 * plane] = 0.25f * o2;
-            rgba[o + 3 * plane] = 0.25f * o3;
+        const size_t plane = (size_t)H * H;
+        const size_t ob = ((size_t)b * (NC + 1) * H + (row >> 1)) * H + (col >> 1);
+#pragma unroll
+        for (int c = 0; c <= NC; ++c) {
+            float v = inimg ? o[c] : 0.f;
+            v += __shfl_xor(v, 1);
+            v += __shfl_xor(v, 2);
+            if (sub == 0 && inimg) rgba[ob + c * plane] = 0.25f * v;
         }
     } else if (inimg) {
-        const size_t o = ((size_t)b * 4 * S + row) * S + col;
+        const size_t ob = ((size_t)b * (NC + 1) * S + row) * S + col;
         const size_t plane = (size_t)S * S;
-        rgba[o] = o0;
-        rgba[o + plane] = o1;
-        rgba[o + 2 * plane] = o2;
-        rgba[o + 3 * plane] = o3;
+#pragma unroll
+        for (int c = 0; c <= NC; ++c) rgba[ob + c * plane] = o[c];
     }
     SV3D_STAMP(6);
 #ifdef SV3D_TRACE
@@ -778,7 +790,9 @@ __global__ __launch_bounds__(kThreads) void raster_backward_kernel(
     const bool staged = tex_staged(Ts);
     float *s_tex = s_dyn + wave * tex_lds_floats(Ts);
     float *s_val = s_tex + tex_grad_floats(Ts);
-    float tv[9];
+    constexpr int NC = mode_channels(MODE);     // colour channels
+    constexpr int PP = MODE == SV3D_TEX_NONE ? 1 : (NC == 3 ? 6 : 12);   // saved floats per pixel
+    float tv[3 * NC];                           // VERTEX modes: the face's per-corner colours
     if (MODE == SV3D_TEX_SURFACE) {
         for (int i = lane; i < ncopy * Ts * 3; i += 64) s_tex[i] = 0.f;
         if (staged) {
@@ -787,15 +801,17 @@ __global__ __launch_bounds__(kThreads) void raster_backward_kernel(
                 reinterpret_cast<float4 *>(s_val)[i] = make_float4(tp[0], tp[1], tp[2], 0.f);
             }
         }
-    } else if (MODE == SV3D_TEX_VERTEX) {
+    } else if (mode_vertex(MODE)) {
 #pragma unroll
-        for (int i = 0; i < 9; ++i) tv[i] = tex[(size_t)gf * 9 + i];
+        for (int i = 0; i < 3 * NC; ++i) tv[i] = tex[(size_t)gf * (3 * NC) + i];
     }
 
     float acc[9];
-    float tacc[9];
+    float tacc[3 * NC];
 #pragma unroll
-    for (int i = 0; i < 9; ++i) { acc[i] = 0.f; tacc[i] = 0.f; }
+    for (int i = 0; i < 9; ++i) acc[i] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 3 * NC; ++i) tacc[i] = 0.f;
 
     // Lanes enumerate the box row-major, 64 pixels per step.  (rx, ry) = position inside the box,
     // kept as exact small integers in fp32 and advanced by 64 pixels per step with at most one
@@ -805,7 +821,7 @@ __global__ __launch_bounds__(kThreads) void raster_backward_kernel(
     const float step = 2.f * P.inv_S;
     float xp0, yp0;
     pixel_centre(col0, row0, S, P.inv_S, xp0, yp0);
-    const float *saved_b = saved + (size_t)b * S * S * (MODE == SV3D_TEX_NONE ? 1 : 6);
+    const float *saved_b = saved + (size_t)b * S * S * PP;
     const int H = S / P.aa;
     const float gscale = P.aa == 2 ? 0.25f : 1.f;
     const float adv_y = bw > 0 ? (float)(64 / bw) : 0.f, adv_x = bw > 0 ? (float)(64 % bw) : 0.f;
@@ -820,12 +836,12 @@ __global__ __launch_bounds__(kThreads) void raster_backward_kernel(
     const float kx0 = (float)(2 * col0 + 1 - S), ky0 = (float)(2 * (S - 1 - row0) + 1 - S), fS = (float)S;
     struct PixIn {
         float xp, yp, xl, yl;
-        float A, ssum, m, cr, cg, cb;       // saved: 1 - alpha product, softmax sum, max, RGB
-        float ga, g0, g1, g2;               // dL/d(alpha, R, G, B) of the output pixel
+        float A, ssum, m, col[NC];          // saved: 1 - alpha product, softmax sum, max, colours
+        float ga, gch[NC];                  // dL/d(alpha, colours) of the output pixel
         bool valid;
     };
     const size_t plane = (size_t)H * H;
-    const float *grad_b = grad_rgba + (size_t)b * 4 * plane;     // RGBA planes of image b
+    const float *grad_b = grad_rgba + (size_t)b * (NC + 1) * plane;     // colour + alpha planes of image b
     auto fetch = [&]() {                            // inputs of the pixel at the current (rx, ry)
         PixIn in;
         in.valid = ry_f < bh_f;
@@ -841,15 +857,27 @@ __global__ __launch_bounds__(kThreads) void raster_backward_kernel(
         const unsigned prow = (unsigned)(row0 + (int)cy), pcol = (unsigned)(col0 + (int)cx);
         const unsigned pix = prow * (unsigned)S + pcol;
         const unsigned gpix = P.aa == 2 ? (prow >> 1) * (unsigned)H + (pcol >> 1) : pix;
-        in.ssum = in.m = in.cr = in.cg = in.cb = in.g0 = in.g1 = in.g2 = 0.f;
-        in.ga = grad_b[gpix + 3 * plane];
+        in.ssum = in.m = 0.f;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) in.col[c] = in.gch[c] = 0.f;
+        in.ga = grad_b[gpix + NC * plane];
         if (MODE == SV3D_TEX_NONE) {
             in.A = saved_b[pix];
-        } else {
+        } else if (NC == 3) {
             const float2 *sp = (const float2 *)(saved_b + pix * 6u);
             const float2 a0 = sp[0], a1 = sp[1], a2 = sp[2];
-            in.A = a0.x; in.ssum = a0.y; in.m = a1.x; in.cr = a1.y; in.cg = a2.x; in.cb = a2.y;
-            in.g0 = grad_b[gpix]; in.g1 = grad_b[gpix + plane]; in.g2 = grad_b[gpix + 2 * plane];
+            in.A = a0.x; in.ssum = a0.y; in.m = a1.x; in.col[0] = a1.y; in.col[1] = a2.x; in.col[2] = a2.y;
+        } else {
+            const float4 *sp = (const float4 *)(saved_b + pix * 12u);
+            const float4 a0 = sp[0], a1 = sp[1], a2 = sp[2];
+            in.A = a0.x; in.ssum = a0.y; in.m = a0.z;
+            const float cs[8] = {a0.w, a1.x, a1.y, a1.z, a1.w, a2.x, a2.y, a2.z};
+#pragma unroll
+            for (int c = 0; c < NC; ++c) in.col[c] = cs[c < 8 ? c : 7];
+        }
+        if (MODE != SV3D_TEX_NONE) {
+#pragma unroll
+            for (int c = 0; c < NC; ++c) in.gch[c] = grad_b[gpix + c * plane];
         }
         // advance to the pixel 64 positions further
         rx_f += adv_x;
@@ -869,12 +897,13 @@ __global__ __launch_bounds__(kThreads) void raster_backward_kernel(
         const bool valid = in.valid;
         // fold the gradient with the aggregates: g_alpha A and g_k / ssum
         const float P0 = in.A * (in.ga * gscale);
-        float G0 = 0.f, G1 = 0.f, G2 = 0.f;
+        float G[NC];
         const float mfin = in.m;
         if (MODE != SV3D_TEX_NONE) {
             float is = rcp(in.ssum);
             is = is * (2.f - in.ssum * is) * gscale;
-            G0 = in.g0 * is; G1 = in.g1 * is; G2 = in.g2 * is;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) G[c] = in.gch[c] * is;
         }
 
         Pixel px;
@@ -891,43 +920,49 @@ __global__ __launch_bounds__(kThreads) void raster_backward_kernel(
             float tg0 = 0.f, tg1 = 0.f, tg2 = 0.f;
             if (contrib) {
                 const float ez = ex2((d.zn - mfin) * P.l2e_over_gamma);
-                float k0, k1, k2;
+                float kc[NC];
                 int tid = 0;
                 if (MODE == SV3D_TEX_SURFACE) {
                     tid = texel_index(d.n0, d.n1, d.n2, P.R);
                     if (staged) {
                         const float4 tv4 = reinterpret_cast<const float4 *>(s_val)[tid];
-                        k0 = tv4.x; k1 = tv4.y; k2 = tv4.z;
+                        kc[0] = tv4.x; kc[1] = tv4.y; kc[2] = tv4.z;
                     } else {
                         const float *tp = tex + ((size_t)gf * Ts + tid) * 3;
-                        k0 = tp[0]; k1 = tp[1]; k2 = tp[2];
+                        kc[0] = tp[0]; kc[1] = tp[1]; kc[2] = tp[2];
                     }
                 } else {
-                    k0 = d.n0 * tv[0] + d.n1 * tv[3] + d.n2 * tv[6];
-                    k1 = d.n0 * tv[1] + d.n1 * tv[4] + d.n2 * tv[7];
-                    k2 = d.n0 * tv[2] + d.n1 * tv[5] + d.n2 * tv[8];
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) kc[c] = d.n0 * tv[c] + d.n1 * tv[NC + c] + d.n2 * tv[2 * NC + c];
                 }
                 // sum_k g_k (colour_k - pixel_k) / ssum, differences first: where this face
                 // dominates the pixel the two colours nearly cancel
-                const float S1 = G0 * (k0 - in.cr) + G1 * (k1 - in.cg) + G2 * (k2 - in.cb);
+                float S1 = 0.f;
+#pragma unroll
+                for (int c = 0; c < NC; ++c) S1 = fmaf(G[c], kc[c] - in.col[c], S1);
                 const float De = g.D * ez;
                 gx += De * g.omD * S1;                               // through D of the softmax weight
                 const float gz = -(De * S1) * P.inv_gamma * P.inv_range;   // dL/dzp
-                const float gc0 = G0 * De, gc1 = G1 * De, gc2 = G2 * De;   // dL/dcolour
+                float gc[NC];                                        // dL/dcolour
+#pragma unroll
+                for (int c = 0; c < NC; ++c) gc[c] = G[c] * De;
                 const float zp2 = d.zp * d.zp;
                 acc[2] += gz * zp2 * d.n0 * r.iz0 * r.iz0;
                 acc[5] += gz * zp2 * d.n1 * r.iz1 * r.iz1;
                 acc[8] += gz * zp2 * d.n2 * r.iz2 * r.iz2;
                 float gn0 = -gz * zp2 * r.iz0, gn1 = -gz * zp2 * r.iz1, gn2 = -gz * zp2 * r.iz2;
                 if (MODE == SV3D_TEX_SURFACE) {
-                    ttid = tid; tg0 = gc0; tg1 = gc1; tg2 = gc2;
+                    ttid = tid; tg0 = gc[0]; tg1 = gc[1]; tg2 = gc[2];
                 } else {
-                    tacc[0] += d.n0 * gc0; tacc[1] += d.n0 * gc1; tacc[2] += d.n0 * gc2;
-                    tacc[3] += d.n1 * gc0; tacc[4] += d.n1 * gc1; tacc[5] += d.n1 * gc2;
-                    tacc[6] += d.n2 * gc0; tacc[7] += d.n2 * gc1; tacc[8] += d.n2 * gc2;
-                    gn0 += gc0 * tv[0] + gc1 * tv[1] + gc2 * tv[2];
-                    gn1 += gc0 * tv[3] + gc1 * tv[4] + gc2 * tv[5];
-                    gn2 += gc0 * tv[6] + gc1 * tv[7] + gc2 * tv[8];
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) {
+                        tacc[c] = fmaf(d.n0, gc[c], tacc[c]);
+                        tacc[NC + c] = fmaf(d.n1, gc[c], tacc[NC + c]);
+                        tacc[2 * NC + c] = fmaf(d.n2, gc[c], tacc[2 * NC + c]);
+                        gn0 = fmaf(gc[c], tv[c], gn0);
+                        gn1 = fmaf(gc[c], tv[NC + c], gn1);
+                        gn2 = fmaf(gc[c], tv[2 * NC + c], gn2);
+                    }
                 }
                 // through the normalisation n = clamp(w)/sum and the clamp
                 const float dotn = gn0 * d.n0 + gn1 * d.n1 + gn2 * d.n2;
@@ -985,13 +1020,11 @@ __global__ __launch_bounds__(kThreads) void raster_backward_kernel(
                 for (int c = 1; c < ncopy; ++c) t += s_tex[c * Ts * 3 + i];
                 gtex[(size_t)gf * Ts * 3 + i] = t;
             }
-        } else if (MODE == SV3D_TEX_VERTEX) {
-            float tt[9];
+        } else if (mode_vertex(MODE)) {
 #pragma unroll
-            for (int i = 0; i < 9; ++i) tt[i] = wave_sum_lane63(tacc[i]);
-            if (lane == 63) {
-#pragma unroll
-                for (int i = 0; i < 9; ++i) gtex[(size_t)gf * 9 + i] = tt[i];
+            for (int i = 0; i < 3 * NC; ++i) {
+                const float t = wave_sum_lane63(tacc[i]);
+                if (lane == 63) gtex[(size_t)gf * (3 * NC) + i] = t;
             }
         }
     }
@@ -1006,7 +1039,7 @@ int make_dev_params(const sv3d_raster_params *p, DevParams &d)
     if (p->batch <= 0 || p->num_faces <= 0 || p->raster_size <= 0) return SV3D_ERR_INVALID_ARG;
     if (p->aa != 1 && p->aa != 2) return SV3D_ERR_INVALID_ARG;
     if (p->aa == 2 && (p->raster_size & 1)) return SV3D_ERR_INVALID_ARG;
-    if (p->texture_mode < SV3D_TEX_NONE || p->texture_mode > SV3D_TEX_VERTEX) return SV3D_ERR_INVALID_ARG;
+    if (p->texture_mode < SV3D_TEX_NONE || p->texture_mode > SV3D_TEX_VERTEX8) return SV3D_ERR_INVALID_ARG;
     if (p->texture_mode == SV3D_TEX_SURFACE && p->texture_res <= 0) return SV3D_ERR_INVALID_ARG;
     if (!(p->sigma > 0.f) || !(p->gamma > 0.f) || !(p->dist_eps > 0.f) || !(p->dist_eps < 1.f))
         return SV3D_ERR_INVALID_ARG;
@@ -1035,7 +1068,10 @@ int make_dev_params(const sv3d_raster_params *p, DevParams &d)
 }
 
 inline size_t rec_floats(const DevParams &d) { return (size_t)d.B * d.F * kRec; }
-inline int saved_per_pixel(const DevParams &d) { return d.mode == SV3D_TEX_NONE ? 1 : 6; }
+inline int saved_per_pixel(const DevParams &d)
+{
+    return d.mode == SV3D_TEX_NONE ? 1 : (d.mode == SV3D_TEX_VERTEX8 ? 12 : 6);
+}
 inline size_t backward_ws_need(const DevParams &)
 {
     // the backward folds the incoming gradient with the saved aggregates on the fly
@@ -1117,7 +1153,8 @@ int raster_forward_impl(const sv3d_raster_params *p, const float *face_vertices,
     } while (0)
     if (d.mode == SV3D_TEX_NONE) SV3D_LAUNCH_FWD(SV3D_TEX_NONE);
     else if (d.mode == SV3D_TEX_SURFACE) SV3D_LAUNCH_FWD(SV3D_TEX_SURFACE);
-    else SV3D_LAUNCH_FWD(SV3D_TEX_VERTEX);
+    else if (d.mode == SV3D_TEX_VERTEX) SV3D_LAUNCH_FWD(SV3D_TEX_VERTEX);
+    else SV3D_LAUNCH_FWD(SV3D_TEX_VERTEX8);
 #undef SV3D_LAUNCH_FWD2
 #undef SV3D_LAUNCH_FWD
     if (ev_stop) (void)hipEventRecord(ev_stop, s);
@@ -1155,7 +1192,8 @@ int raster_backward_impl(const sv3d_raster_params *p, const float *textures, con
     } while (0)
     if (d.mode == SV3D_TEX_NONE) SV3D_LAUNCH_BWD(SV3D_TEX_NONE);
     else if (d.mode == SV3D_TEX_SURFACE) SV3D_LAUNCH_BWD(SV3D_TEX_SURFACE);
-    else SV3D_LAUNCH_BWD(SV3D_TEX_VERTEX);
+    else if (d.mode == SV3D_TEX_VERTEX) SV3D_LAUNCH_BWD(SV3D_TEX_VERTEX);
+    else SV3D_LAUNCH_BWD(SV3D_TEX_VERTEX8);
 #undef SV3D_LAUNCH_BWD
     if (ev_stop) (void)hipEventRecord(ev_stop, s);
     return launch_status();

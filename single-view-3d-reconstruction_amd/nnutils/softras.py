@@ -100,9 +100,9 @@ class SoftNeuralRenderer(torch.nn.Module):
     # The reference's training step renders the same (vertices, faces, cams) ten times per
     # iteration (main.py:417-426): a silhouette, an RGB image, and Np part maps one at a time,
     # each part map copied into three identical colour channels of which one is kept.  The
-    # silhouette is the alpha channel every colour pass computes anyway, and the three colour
-    # channels of a vertex-colour pass are independent, so the same images come out of
-    # 1 + ceil(Np / 3) passes.
+    # silhouette is the alpha channel every colour pass computes anyway, and the colour channels
+    # of a vertex-colour pass are independent, so the same images come out of 1 + ceil(Np / 8)
+    # passes (the kernels' eight-channel vertex mode).
     def forward_with_mask(self, vertices, faces, cams, textures):
         """(forward(vertices, faces, cams, textures), forward(vertices, faces, cams)) from one
         pass: RGB [B,3,H,W] and the silhouette [B,H,W]."""
@@ -115,11 +115,29 @@ class SoftNeuralRenderer(torch.nn.Module):
     def render_parts(self, vertices, faces, cams, part_maps):
         """part_maps [B,V,Np] -> [B,Np,H,W], equal to stacking
         forward(vertices, faces, cams, part_maps[:, :, k:k+1].repeat(1, 1, 3))[:, 0:1] over k
-        (main.py:422-426), three maps per rasterizer pass.  Needs texture_type='vertex'."""
+        (main.py:422-426).  Eight maps per rasterizer pass (the kernels' eight-channel vertex
+        mode) when the camera stage is the fused one, else three.  Needs texture_type='vertex'."""
         if not self.part_seg:
             raise ValueError("render_parts needs a renderer built with texture_type='vertex'")
         n = part_maps.shape[2]
+        stage = self._camera_stage()
         out = []
+        if stage is not None:
+            r = self.renderer.rasterizer
+            self.mask_only = False
+            self.renderer.set_texture_mode('vertex')
+            for k in range(0, n, 8):
+                group = part_maps[:, :, k:k + 8]
+                if group.shape[2] < 8:
+                    group = torch.nn.functional.pad(group, (0, 8 - group.shape[2]))
+                colours = sv3d.face_gather_n(group, faces)
+                img = sv3d.render(vertices, cams, faces, colours, r.image_size, texture_type='vertex8',
+                                  offset_z=self.offset_z, scale=stage[0], shift=stage[1],
+                                  anti_aliasing=r.anti_aliasing, background_color=r.background_color,
+                                  near=r.near, far=r.far, eps=r.eps, sigma_val=r.sigma_val,
+                                  dist_eps=r.dist_eps, gamma_val=r.gamma_val, fill_back=r.fill_back)
+                out.append(img[:, :min(8, n - k)])
+            return out[0] if len(out) == 1 else torch.cat(out, dim=1)
         for k in range(0, n, 3):
             group = part_maps[:, :, k:k + 3]
             if group.shape[2] < 3:

@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsv3d_hip.so")
 
-SV3D_TEX_NONE, SV3D_TEX_SURFACE, SV3D_TEX_VERTEX = 0, 1, 2
+SV3D_TEX_NONE, SV3D_TEX_SURFACE, SV3D_TEX_VERTEX, SV3D_TEX_VERTEX8 = 0, 1, 2, 3
 
 EXPORTS = (
     "sv3d_strerror", "sv3d_abi_version", "sv3d_raster_sizes", "sv3d_raster_forward",
@@ -18,6 +18,7 @@ EXPORTS = (
     "sv3d_chamfer_forward", "sv3d_chamfer_backward",
     "sv3d_face_gather", "sv3d_face_scatter",
     "sv3d_project_gather", "sv3d_project_scatter", "sv3d_render_forward",
+    "sv3d_face_gather_n", "sv3d_face_scatter_n",
 )
 
 
@@ -76,6 +77,8 @@ def lib():
         f3 = ctypes.POINTER(ctypes.c_float)
         L.sv3d_face_gather.argtypes = [vp, vp, i32, i32, i32, i32, f3, f3, vp, vp]
         L.sv3d_face_scatter.argtypes = [vp, vp, i32, i32, i32, i32, f3, vp, vp]
+        L.sv3d_face_gather_n.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp, vp]
+        L.sv3d_face_scatter_n.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp, vp]
         mp = ctypes.POINTER(MeshInput)
         L.sv3d_project_gather.argtypes = [mp, i32, i32, vp, vp]
         L.sv3d_project_scatter.argtypes = [mp, i32, i32, vp, vp, vp, vp]

@@ -40,6 +40,21 @@ def _params(fv, raster_size, aa, texture_mode, texture_res, double_side, backgro
                          double_side, background, near, far, eps, sigma, dist_eps, gamma)
 
 
+def _channels(texture_mode):
+    """Planes of the rendered image: colour channels + alpha."""
+    return 9 if texture_mode == L.SV3D_TEX_VERTEX8 else 4
+
+
+def _saved_per_pixel(texture_mode):
+    return 1 if texture_mode == L.SV3D_TEX_NONE else (12 if texture_mode == L.SV3D_TEX_VERTEX8 else 6)
+
+
+def _texture_shape(B, F, texture_mode, texture_res):
+    if texture_mode == L.SV3D_TEX_SURFACE:
+        return (B, F, texture_res * texture_res, 3)
+    return (B, F, 3, 8) if texture_mode == L.SV3D_TEX_VERTEX8 else (B, F, 3, 3)
+
+
 def _check_raster_inputs(fv, tex, texture_mode, texture_res):
     if fv.dim() != 4 or fv.shape[2:] != (3, 3):
         raise ValueError("face_vertices must be [B,F,3,3], got %s" % (tuple(fv.shape),))
@@ -47,8 +62,7 @@ def _check_raster_inputs(fv, tex, texture_mode, texture_res):
         return
     if tex is None:
         raise ValueError("textures required for texture_mode %d" % texture_mode)
-    want = (fv.shape[0], fv.shape[1], texture_res * texture_res, 3) \
-        if texture_mode == L.SV3D_TEX_SURFACE else (fv.shape[0], fv.shape[1], 3, 3)
+    want = _texture_shape(fv.shape[0], fv.shape[1], texture_mode, texture_res)
     if tuple(tex.shape) != want:
         raise ValueError("textures must be %s, got %s" % (want, tuple(tex.shape)))
 
@@ -67,7 +81,7 @@ def soft_rasterize_op(face_vertices: Tensor, textures: Optional[Tensor], raster_
     rec_b, saved_b, _ = L.raster_sizes(p)
     H = raster_size // aa
     with torch.cuda.device(fv.device):
-        rgba = torch.empty((fv.shape[0], 4, H, H), dtype=torch.float32, device=fv.device)
+        rgba = torch.empty((fv.shape[0], _channels(texture_mode), H, H), dtype=torch.float32, device=fv.device)
         rec = torch.empty(rec_b // 4, dtype=torch.float32, device=fv.device)
         saved = torch.empty(saved_b // 4, dtype=torch.float32, device=fv.device)
         L.check(L.lib().sv3d_raster_forward(ctypes.byref(p), _ptr(fv), _ptr(tex), _ptr(rgba),
@@ -81,8 +95,8 @@ def _(face_vertices, textures, raster_size, aa, texture_mode, texture_res, doubl
       background, near, far, eps, sigma, dist_eps, gamma):
     B, F = face_vertices.shape[0], face_vertices.shape[1]
     H = raster_size // aa
-    per = 1 if texture_mode == L.SV3D_TEX_NONE else 6
-    return (face_vertices.new_empty((B, 4, H, H), dtype=torch.float32),
+    per = _saved_per_pixel(texture_mode)
+    return (face_vertices.new_empty((B, _channels(texture_mode), H, H), dtype=torch.float32),
             face_vertices.new_empty((B * F * 34,), dtype=torch.float32),
             face_vertices.new_empty((B * raster_size * raster_size * per,), dtype=torch.float32))
 
@@ -157,7 +171,8 @@ def soft_rasterize(face_vertices, textures=None, image_size=256, *, anti_aliasin
     """Soft rasterization of `face_vertices` [B,F,3,3] -> RGBA [B,4,image_size,image_size].
 
     `textures`: None renders the silhouette only (RGB = background); [B,F,R*R,3] for
-    texture_type 'surface'; [B,F,3,3] per-corner colours for 'vertex'.  With
+    texture_type 'surface'; [B,F,3,3] per-corner colours for 'vertex'; [B,F,3,8] eight scalar
+    per-corner channels for 'vertex8' (output [B,9,H,W]: the eight channels, then alpha).  With
     `anti_aliasing` fragments are evaluated at twice the resolution and average-pooled
     inside the kernel.
     """
@@ -171,6 +186,8 @@ def soft_rasterize(face_vertices, textures=None, image_size=256, *, anti_aliasin
             raise ValueError("surface textures need a square texel count, got %d" % textures.shape[2])
     elif texture_type == "vertex":
         mode, res = L.SV3D_TEX_VERTEX, 1
+    elif texture_type == "vertex8":
+        mode, res = L.SV3D_TEX_VERTEX8, 1
     else:
         raise ValueError("unknown texture_type %r" % (texture_type,))
     if _plain(face_vertices, textures) and face_vertices.is_cuda:
@@ -421,7 +438,7 @@ def render_op(vertices: Tensor, cams: Tensor, faces: Tensor, textures: Optional[
     v, c, f = _f32c(vertices), _f32c(cams), faces.contiguous()
     B, F = v.shape[0], f.shape[1]
     if texture_mode != L.SV3D_TEX_NONE:
-        want = (B, F, texture_res * texture_res, 3) if texture_mode == L.SV3D_TEX_SURFACE else (B, F, 3, 3)
+        want = _texture_shape(B, F, texture_mode, texture_res)
         if textures is None or tuple(textures.shape) != want:
             raise ValueError("textures must be %s" % (want,))
     tex = _f32c(textures) if texture_mode != L.SV3D_TEX_NONE else None
@@ -430,7 +447,7 @@ def render_op(vertices: Tensor, cams: Tensor, faces: Tensor, textures: Optional[
     rec_b, saved_b, _ = L.raster_sizes(p)
     H = raster_size // aa
     with torch.cuda.device(v.device):
-        rgba = torch.empty((B, 4, H, H), dtype=torch.float32, device=v.device)
+        rgba = torch.empty((B, _channels(texture_mode), H, H), dtype=torch.float32, device=v.device)
         rec = torch.empty(rec_b // 4, dtype=torch.float32, device=v.device)
         saved = torch.empty(saved_b // 4, dtype=torch.float32, device=v.device)
         m = L.make_mesh_input(v, c, f, offset_z, scale, shift)
@@ -444,8 +461,8 @@ def _(vertices, cams, faces, textures, offset_z, scale, shift, raster_size, aa, 
       double_side, background, near, far, eps, sigma, dist_eps, gamma):
     B, F = vertices.shape[0], faces.shape[1]
     H = raster_size // aa
-    per = 1 if texture_mode == L.SV3D_TEX_NONE else 6
-    return (vertices.new_empty((B, 4, H, H), dtype=torch.float32),
+    per = _saved_per_pixel(texture_mode)
+    return (vertices.new_empty((B, _channels(texture_mode), H, H), dtype=torch.float32),
             vertices.new_empty((B * F * 34,), dtype=torch.float32),
             vertices.new_empty((B * raster_size * raster_size * per,), dtype=torch.float32))
 
@@ -532,6 +549,8 @@ def render(vertices, cams, faces, textures=None, image_size=256, *, offset_z=0.0
             raise ValueError("surface textures need a square texel count, got %d" % textures.shape[2])
     elif texture_type == "vertex":
         mode, res = L.SV3D_TEX_VERTEX, 1
+    elif texture_type == "vertex8":
+        mode, res = L.SV3D_TEX_VERTEX8, 1
     else:
         raise ValueError("unknown texture_type %r" % (texture_type,))
     f32 = _faces_i32(faces)
@@ -539,7 +558,7 @@ def render(vertices, cams, faces, textures=None, image_size=256, *, offset_z=0.0
         _check_mesh(vertices, cams, f32)
         B, F = vertices.shape[0], f32.shape[1]
         if mode != L.SV3D_TEX_NONE:
-            want = (B, F, res * res, 3) if mode == L.SV3D_TEX_SURFACE else (B, F, 3, 3)
+            want = _texture_shape(B, F, mode, res)
             if tuple(textures.shape) != want:
                 raise ValueError("textures must be %s" % (want,))
         key = (B, F, int(image_size) * aa, aa, mode, res, bool(fill_back),
@@ -609,7 +628,7 @@ class _RenderFn(torch.autograd.Function):
         B, S, aa = key[0], key[2], key[3]
         dev = x.device
         with torch.cuda.device(dev):
-            rgba = torch.empty((B, 4, S // aa, S // aa), dtype=torch.float32, device=dev)
+            rgba = torch.empty((B, _channels(key[4]), S // aa, S // aa), dtype=torch.float32, device=dev)
             rec = torch.empty(rec_b // 4, dtype=torch.float32, device=dev)
             saved = torch.empty(saved_b // 4, dtype=torch.float32, device=dev)
             if cams is not None:
@@ -684,3 +703,60 @@ class _ChamferFn(torch.autograd.Function):
                                                   _ptr(i2), _ptr(g1), _ptr(g2), _stream(a)),
                     "sv3d_chamfer_backward")
         return (g1.to(ctx.dtypes[0]) if need1 else None, g2.to(ctx.dtypes[1]) if need2 else None)
+
+
+# ---- per-vertex channel gather (part maps) ---------------------------------------------------
+@torch.library.custom_op("sv3d::face_gather_n", mutates_args=(), device_types="cuda")
+def face_gather_n_op(values: Tensor, faces: Tensor) -> Tensor:
+    if values.dim() != 3 or not 1 <= values.shape[2] <= 8:
+        raise ValueError("values must be [B,V,C] with C <= 8, got %s" % (tuple(values.shape),))
+    if faces.dim() != 3 or faces.shape[2] != 3 or faces.dtype != torch.int32 \
+            or faces.shape[0] not in (1, values.shape[0]):
+        raise ValueError("faces must be int32 [B or 1,F,3], got %s %s" % (faces.dtype, tuple(faces.shape)))
+    v, f = _f32c(values), faces.contiguous()
+    B, V, C, F = v.shape[0], v.shape[1], v.shape[2], f.shape[1]
+    with torch.cuda.device(v.device):
+        out = torch.empty((B, F, 3, C), dtype=torch.float32, device=v.device)
+        L.check(L.lib().sv3d_face_gather_n(_ptr(v), _ptr(f), B, V, F, f.shape[0], C, _ptr(out), _stream(v)),
+                "sv3d_face_gather_n")
+    return out
+
+
+@face_gather_n_op.register_fake
+def _(values, faces):
+    return values.new_empty((values.shape[0], faces.shape[1], 3, values.shape[2]), dtype=torch.float32)
+
+
+@torch.library.custom_op("sv3d::face_scatter_n", mutates_args=(), device_types="cuda")
+def face_scatter_n_op(grad_out: Tensor, faces: Tensor, num_vertices: int) -> Tensor:
+    g = _f32c(grad_out)
+    B, F, C = g.shape[0], g.shape[1], g.shape[3]
+    with torch.cuda.device(g.device):
+        out = torch.empty((B, num_vertices, C), dtype=torch.float32, device=g.device)
+        L.check(L.lib().sv3d_face_scatter_n(_ptr(g), _ptr(faces), B, num_vertices, F, faces.shape[0], C,
+                                            _ptr(out), _stream(g)), "sv3d_face_scatter_n")
+    return out
+
+
+@face_scatter_n_op.register_fake
+def _(grad_out, faces, num_vertices):
+    return grad_out.new_empty((grad_out.shape[0], num_vertices, grad_out.shape[3]), dtype=torch.float32)
+
+
+def _gather_n_setup_context(ctx, inputs, output):
+    values, faces = inputs
+    ctx.save_for_backward(faces)
+    ctx.num_vertices, ctx.dtype = values.shape[1], values.dtype
+
+
+def _gather_n_backward(ctx, grad_out):
+    (faces,) = ctx.saved_tensors
+    return face_scatter_n_op(grad_out, faces, ctx.num_vertices).to(ctx.dtype), None
+
+
+face_gather_n_op.register_autograd(_gather_n_backward, setup_context=_gather_n_setup_context)
+
+
+def face_gather_n(values, faces):
+    """out[b,f,k,:] = values[b, faces[b or 0, f, k], :] for C <= 8 channels: [B,V,C] -> [B,F,3,C]."""
+    return face_gather_n_op(values, _faces_i32(faces))

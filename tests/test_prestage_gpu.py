@@ -190,7 +190,7 @@ def test_render_forward_writes_face_vertices_and_validates():
 def test_shared_pass_renders_equal_the_separate_calls():
     """forward_with_mask / render_parts against the 2 + Np separate calls of main.py:417-426."""
     from nnutils.softras import SoftNeuralRenderer
-    B, img, Np = 2, 32, 5
+    B, img, Np = 2, 32, 7
     verts, faces = load_mesh(2)
     v, cams = random_vertices(verts, B, 0).cuda(), random_cams(B, 1).cuda()
     f = faces.long()[None].repeat(B, 1, 1).cuda()

@@ -43,6 +43,8 @@ def _textures(mode, B, F, R, seed=2):
         return torch.rand(B, F, R * R, 3, generator=g)
     if mode == "vertex":
         return torch.rand(B, F, 3, 3, generator=g)
+    if mode == "vertex8":
+        return torch.rand(B, F, 3, 8, generator=g)
     return None
 
 
@@ -94,7 +96,7 @@ def _fp32_floor(fv, tex, img, aa, mode, grad, unstable, want, wfv, wtex, **kw):
 
 def _compare(name, fv, tex, img, aa, mode, fp32_floor=False, grad_tol=None, img_tol=None, **kw):
     B = fv.shape[0]
-    grad = 2 * torch.rand(B, 4, img, img, generator=torch.Generator().manual_seed(4)) - 1
+    grad = 2 * torch.rand(B, 9 if mode == "vertex8" else 4, img, img, generator=torch.Generator().manual_seed(4)) - 1
     want, wfv, wtex, unstable, nact = _oracle(fv, tex, img, aa, mode, grad, **kw)
     got, gfv, gtex = _hip(fv, tex, img, aa, mode, grad, unstable, **kw)
     frac = float(unstable.float().mean())
@@ -407,3 +409,23 @@ def test_parity_seeded_random_configurations(seed):
     tex = _textures(mode, B, faces.shape[0], R, seed=seed)
     _compare("sweep_%d_%s_S%d_aa%d" % (seed, mode, img, aa), fv, tex, img, aa, mode, grad_tol=SWEEP_GRAD_TOL,
              sigma=sigma, gamma=gamma, double_side=double_side, background=bgc)
+
+
+@pytest.mark.parametrize("aa", [False, True])
+def test_parity_eight_channel_vertex_mode(aa):
+    """SV3D_TEX_VERTEX8: eight scalar per-corner channels in one pass (image [B,9,H,W]) against the
+    oracle, and channel by channel against three-channel vertex renders of the same maps."""
+    import sv3d
+    verts, faces = load_mesh(2)
+    fv = camera_space_faces(verts, faces, 2, seed=31)
+    tex = _textures("vertex8", 2, faces.shape[0], 1)
+    got, gfv, gtex = _compare("ico2_vertex8_aa%d" % aa, fv, tex, 32, aa, "vertex8", sigma=3e-5, gamma=1e-3,
+                              background=(0.25, 0.5, 0.75))
+    assert got.shape == (2, 9, 32, 32)
+    # channel c of the one-pass image == channel 0 of a vertex render of map c copied three times
+    for c in (0, 5, 7):
+        three = tex[..., c:c + 1].repeat(1, 1, 1, 3).cuda()
+        ref = sv3d.soft_rasterize(fv.cuda(), three, 32, anti_aliasing=aa, texture_type="vertex", sigma_val=3e-5,
+                                  gamma_val=1e-3, background_color=(0.25, 0.5, 0.75))
+        assert rel_err(got[:, c], ref[:, 0].cpu()) < 1e-6
+        assert rel_err(got[:, 8], ref[:, 3].cpu()) < 1e-6

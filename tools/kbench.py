@@ -30,6 +30,7 @@ CONFIGS = {
     "ref_vert": (64, 256, True, 3, 1e-5, "vertex", 1),
     "hd_rgb": (64, 256, True, 4, 1e-5, "surface", 6),
     "c2_rgb": (8, 256, False, 3, 1e-4, "surface", 6),
+    "ref_vert8": (64, 256, True, 3, 1e-5, "vertex8", 1),    # eight part maps in one pass
 }
 
 
@@ -61,11 +62,11 @@ def main():
         ns = argparse.Namespace(batch=B, image_size=img, subdivide=sub, mode=mode, tex_size=T)
         fv, tex, grad = bench.build_inputs(ns, dev, seed=1000)
         S = img * (2 if aa else 1)
-        m = {"none": 0, "surface": 1, "vertex": 2}[mode]
+        m = {"none": 0, "surface": 1, "vertex": 2, "vertex8": 3}[mode]
         p = L.make_params(B, fv.shape[1], S, 2 if aa else 1, m, T, True, (0, 0, 0), 1, 100, 1e-3, sigma, 1e-10, 1e-4)
         rec_b, saved_b, ws_b = L.raster_sizes(p)
         f32 = dict(dtype=torch.float32, device=dev)
-        rgba = torch.empty((B, 4, img, img), **f32)
+        rgba = torch.empty((B, 9 if mode == "vertex8" else 4, img, img), **f32)
         ws_b = max(ws_b, saved_b)                 # older builds want scratch in every mode
         rec, saved, ws = (torch.empty(n // 4, **f32) for n in (rec_b, saved_b, ws_b))
         gfv = torch.empty_like(fv)
