@@ -37,6 +37,8 @@ def test_opcheck_mesh_and_chamfer_ops():
                           test_utils=TESTS)
     torch.library.opcheck(ops.project_gather_op, (v, cams.requires_grad_(True), f, 5.0, [1.0, -1.0, 1.0],
                                                   [0.0, 0.0, 2.732]), test_utils=TESTS)
+    parts = torch.rand(2, v.shape[1], 8, device="cuda", requires_grad=True)
+    torch.library.opcheck(ops.face_gather_n_op, (parts, f), test_utils=TESTS)
     a = torch.randn(2, 50, 3, device="cuda", requires_grad=True)
     b = torch.randn(2, 70, 3, device="cuda", requires_grad=True)
     torch.library.opcheck(ops.chamfer_nn_op, (a, b), test_utils=TESTS)
