@@ -401,16 +401,74 @@ __device__ inline int wave_inclusive_scan(int v)
 }
 
 // ------------------------------------------------------------------------------------
+// coarse bins (meshes with many faces)
+// ------------------------------------------------------------------------------------
+// Every tile workgroup of the forward tests the pixel boxes of its image's faces; with thousands
+// of faces that scan outweighs the fragment work (5120 faces at 512^2: ~40 % of the forward's
+// instructions).  For such meshes a first kernel lists, per 64x64-pixel bin (4x4 tiles), the
+// faces whose pixel box touches the bin, in face order; a tile then scans its bin's list only.
+constexpr int kBinTiles = 4;                    // tiles per bin side
+constexpr int kBinPix = kBinTiles * kTile;
+
+struct CoarseBins {
+    const unsigned short *list;                 // [B][nbins][cap] face ids, ascending; nullptr = not used
+    const int *count;                           // [B][nbins]
+    int bins_x, nbins, cap;
+};
+
+__global__ __launch_bounds__(kThreads) void raster_coarse_kernel(
+    DevParams P, const uint2 *__restrict__ pbox, unsigned short *__restrict__ list,
+    int *__restrict__ count, int bins_x, int nbins, int cap)
+{
+    __shared__ int s_cnt[4][4];
+    const int b = blockIdx.x / nbins, bin = blockIdx.x - b * nbins;
+    const int by = bin / bins_x, bx = bin - by * bins_x;
+    const int c0 = bx * kBinPix, c1 = c0 + kBinPix - 1, r0 = by * kBinPix, r1 = r0 + kBinPix - 1;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned long long lane_lt = (1ull << lane) - 1ull;
+    const uint2 *pb = pbox + (size_t)b * P.F;
+    unsigned short *out = list + ((size_t)b * nbins + bin) * cap;
+    int base = 0;                               // hits so far (uniform over the workgroup)
+    for (int f0 = 0; f0 < P.F; f0 += 4 * kThreads) {
+        uint2 box[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {           // four loads in flight per thread
+            const int f = f0 + k * kThreads + threadIdx.x;
+            box[k] = f < P.F ? pb[f] : make_uint2(0xffff7fffu, 0xffff7fffu);
+        }
+        unsigned long long mask[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            int a0, a1, b0, b1;
+            unpack_box(box[k], a0, a1, b0, b1);
+            mask[k] = __ballot(!(a1 < c0 || a0 > c1 || b1 < r0 || b0 > r1));
+            if (lane == 0) s_cnt[k][wave] = __popcll(mask[k]);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {           // face order: chunk k, then wave, then lane
+            int off = base;
+            for (int w = 0; w < wave; ++w) off += s_cnt[k][w];
+            if ((mask[k] >> lane) & 1ull)
+                out[off + __popcll(mask[k] & lane_lt)] = (unsigned short)(f0 + k * kThreads + threadIdx.x);
+            base += s_cnt[k][0] + s_cnt[k][1] + s_cnt[k][2] + s_cnt[k][3];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) count[(size_t)b * nbins + bin] = base;
+}
+
+// ------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------
 // SPLIT = 1: four waves, one per 8x8 block of the tile.  SPLIT = 2 (small grids): eight waves, two
 // per block, which take alternate hits of the block's face list and merge their partial pixel
 // states through LDS at the end -- the kernel's span at small batches is its longest single wave
 // (a silhouette-ring block with ~60 faces), and this halves it.
-template <int MODE, int SPLIT, bool LO>
+template <int MODE, int SPLIT, bool LO, bool COARSE>
 __global__ __launch_bounds__(kThreads * SPLIT) void raster_forward_kernel(
     DevParams P, const float4 *__restrict__ rec, const uint2 *__restrict__ pbox,
-    const float *__restrict__ tex, float *__restrict__ rgba, float *__restrict__ saved)
+    const float *__restrict__ tex, float *__restrict__ rgba, float *__restrict__ saved, CoarseBins CB)
 {
     constexpr int NT = kThreads * SPLIT;        // threads per workgroup
     constexpr int NW = 4 * SPLIT;               // waves per workgroup
@@ -564,15 +622,24 @@ __global__ __launch_bounds__(kThreads * SPLIT) void raster_forward_kernel(
     // mask popcounts for itself (DPP prefix sum, no second barrier), which gives each hit its
     // list position, and the list is consumed in windows of kListCap faces.
     const int tc1 = tile_c0 + kTile - 1, tr1 = tile_r0 + kTile - 1;
+    // candidates: all faces, or the faces listed for this tile's coarse bin
+    const unsigned short *cl = nullptr;
+    int ncand = F;
+    if (COARSE) {
+        const size_t bi = (size_t)b * CB.nbins + (tile_r0 / kBinPix) * CB.bins_x + tile_c0 / kBinPix;
+        cl = CB.list + bi * CB.cap;
+        ncand = CB.count[bi];
+    }
     SV3D_STAMP(0);
-    for (int fbase = 0; fbase < F; fbase += 64 * 64) {
-        const int nmask = (min(F - fbase, 64 * 64) + 63) >> 6;      // at most 64 masks per pass
+    for (int fbase = 0; fbase < ncand; fbase += 64 * 64) {
+        const int nmask = (min(ncand - fbase, 64 * 64) + 63) >> 6;  // at most 64 masks per pass
         for (int m0 = wave; m0 < nmask; m0 += 8 * NW) {             // eight masks per wave per trip
             uint2 bx[8];
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
-                const int f = fbase + (m0 + NW * k) * 64 + lane;
-                bx[k] = f < F ? pbox_b[f] : make_uint2(0xffff7fffu, 0xffff7fffu);   // empty box
+                const int cand = fbase + (m0 + NW * k) * 64 + lane;
+                const int f = cand < ncand ? (COARSE ? (int)cl[cand] : cand) : -1;
+                bx[k] = f >= 0 ? pbox_b[f] : make_uint2(0xffff7fffu, 0xffff7fffu);   // empty box
             }
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
@@ -601,7 +668,10 @@ __global__ __launch_bounds__(kThreads * SPLIT) void raster_forward_kernel(
                 const int off = __builtin_amdgcn_readlane(excl, mi);
                 if ((mask >> lane) & 1ull) {
                     const int pos = off + __popcll(mask & lane_lt) - win;
-                    if (pos >= 0 && pos < kListCap) s_ids[pos] = fbase + mi * 64 + lane;
+                    if (pos >= 0 && pos < kListCap) {
+                        const int cand = fbase + mi * 64 + lane;
+                        s_ids[pos] = COARSE ? (int)cl[cand] : cand;
+                    }
                 }
             }
             __syncthreads();
@@ -1078,6 +1148,18 @@ inline size_t backward_ws_need(const DevParams &)
     return 0;
 }
 
+// Coarse bins are built for meshes with many faces (ids must fit 16 bits); their storage follows the
+// pixel boxes in the face_rec buffer: counts [B][nbins] int32, then lists [B][nbins][cap] uint16.
+inline bool coarse_enabled(const DevParams &d) { return d.F >= 2048 && d.F <= 65535 && d.S > kBinPix; }
+inline int coarse_bins_x(const DevParams &d) { return (d.S + kBinPix - 1) / kBinPix; }
+inline int coarse_cap(const DevParams &d) { return (d.F + 7) & ~7; }
+inline size_t coarse_bytes(const DevParams &d)
+{
+    if (!coarse_enabled(d)) return 0;
+    const size_t nb = (size_t)d.B * coarse_bins_x(d) * coarse_bins_x(d);
+    return nb * sizeof(int) + nb * coarse_cap(d) * sizeof(unsigned short);
+}
+
 inline int launch_status()
 {
     return hipGetLastError() == hipSuccess ? SV3D_OK : SV3D_ERR_LAUNCH;
@@ -1092,7 +1174,8 @@ extern "C" int sv3d_raster_sizes(const sv3d_raster_params *p, size_t *face_rec_b
     const int st = make_dev_params(p, d);
     if (st != SV3D_OK) return st;
     const size_t pix = (size_t)d.B * d.S * d.S * saved_per_pixel(d) * sizeof(float);
-    if (face_rec_bytes) *face_rec_bytes = rec_floats(d) * sizeof(float) + (size_t)d.B * d.F * sizeof(uint2);
+    if (face_rec_bytes)
+        *face_rec_bytes = rec_floats(d) * sizeof(float) + (size_t)d.B * d.F * sizeof(uint2) + coarse_bytes(d);
     if (pixel_saved_bytes) *pixel_saved_bytes = pix;
     if (backward_ws_bytes) *backward_ws_bytes = backward_ws_need(d);
     return SV3D_OK;
@@ -1136,20 +1219,32 @@ int raster_forward_impl(const sv3d_raster_params *p, const float *face_vertices,
     const int tiles = (d.S + kTile - 1) / kTile;
     dim3 grid((unsigned)tiles * tiles * d.B);
     float *saved = static_cast<float *>(pixel_saved);
+    CoarseBins cb = {nullptr, nullptr, 0, 0, 0};
+    const bool coarse = coarse_enabled(d);
+    if (coarse) {
+        const int bx = coarse_bins_x(d), nbins = bx * bx, cap = coarse_cap(d);
+        int *count = reinterpret_cast<int *>(pbox + nf);
+        unsigned short *list = reinterpret_cast<unsigned short *>(count + (size_t)d.B * nbins);
+        hipLaunchKernelGGL(raster_coarse_kernel, dim3((unsigned)(d.B * nbins)), dim3(kThreads), 0, s, d, pbox,
+                           list, count, bx, nbins, cap);
+        cb = {list, count, bx, nbins, cap};
+    }
     if (ev_start) (void)hipEventRecord(ev_start, s);
     // two waves per block while the grid is small enough that single waves set the kernel's span;
     // the remainder-carrying variants when S is not a power of two
     const bool split = (long)tiles * tiles * d.B <= 4096;
     const bool lo = (d.S & (d.S - 1)) != 0;
-#define SV3D_LAUNCH_FWD2(M, SP, LO_)                                                                   \
-    hipLaunchKernelGGL((raster_forward_kernel<M, SP, LO_>), grid, dim3(SP * kThreads), 0, s, d, rec, pbox, \
-                       textures, rgba_out, saved)
+#define SV3D_LAUNCH_FWD2(M, SP, LO_, CO_)                                                              \
+    hipLaunchKernelGGL((raster_forward_kernel<M, SP, LO_, CO_>), grid, dim3(SP * kThreads), 0, s, d, rec,  \
+                       pbox, textures, rgba_out, saved, cb)
 #define SV3D_LAUNCH_FWD(M)                                                                             \
     do {                                                                                               \
-        if (split && lo) SV3D_LAUNCH_FWD2(M, 2, true);                                                 \
-        else if (split) SV3D_LAUNCH_FWD2(M, 2, false);                                                 \
-        else if (lo) SV3D_LAUNCH_FWD2(M, 1, true);                                                     \
-        else SV3D_LAUNCH_FWD2(M, 1, false);                                                            \
+        if (coarse && lo) SV3D_LAUNCH_FWD2(M, 1, true, true);                                          \
+        else if (coarse) SV3D_LAUNCH_FWD2(M, 1, false, true);                                          \
+        else if (split && lo) SV3D_LAUNCH_FWD2(M, 2, true, false);                                     \
+        else if (split) SV3D_LAUNCH_FWD2(M, 2, false, false);                                          \
+        else if (lo) SV3D_LAUNCH_FWD2(M, 1, true, false);                                              \
+        else SV3D_LAUNCH_FWD2(M, 1, false, false);                                                     \
     } while (0)
     if (d.mode == SV3D_TEX_NONE) SV3D_LAUNCH_FWD(SV3D_TEX_NONE);
     else if (d.mode == SV3D_TEX_SURFACE) SV3D_LAUNCH_FWD(SV3D_TEX_SURFACE);

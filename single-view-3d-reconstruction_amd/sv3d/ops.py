@@ -96,8 +96,10 @@ def _(face_vertices, textures, raster_size, aa, texture_mode, texture_res, doubl
     B, F = face_vertices.shape[0], face_vertices.shape[1]
     H = raster_size // aa
     per = _saved_per_pixel(texture_mode)
+    rec_b = L.raster_sizes(L.make_params(B, F, raster_size, aa, texture_mode, texture_res, double_side,
+                                         background, near, far, eps, sigma, dist_eps, gamma))[0]
     return (face_vertices.new_empty((B, _channels(texture_mode), H, H), dtype=torch.float32),
-            face_vertices.new_empty((B * F * 34,), dtype=torch.float32),
+            face_vertices.new_empty((rec_b // 4,), dtype=torch.float32),
             face_vertices.new_empty((B * raster_size * raster_size * per,), dtype=torch.float32))
 
 
@@ -462,8 +464,10 @@ def _(vertices, cams, faces, textures, offset_z, scale, shift, raster_size, aa, 
     B, F = vertices.shape[0], faces.shape[1]
     H = raster_size // aa
     per = _saved_per_pixel(texture_mode)
+    rec_b = L.raster_sizes(L.make_params(B, F, raster_size, aa, texture_mode, texture_res, double_side,
+                                         background, near, far, eps, sigma, dist_eps, gamma))[0]
     return (vertices.new_empty((B, _channels(texture_mode), H, H), dtype=torch.float32),
-            vertices.new_empty((B * F * 34,), dtype=torch.float32),
+            vertices.new_empty((rec_b // 4,), dtype=torch.float32),
             vertices.new_empty((B * raster_size * raster_size * per,), dtype=torch.float32))
 
 

@@ -429,3 +429,24 @@ def test_parity_eight_channel_vertex_mode(aa):
                                   gamma_val=1e-3, background_color=(0.25, 0.5, 0.75))
         assert rel_err(got[:, c], ref[:, 0].cpu()) < 1e-6
         assert rel_err(got[:, 8], ref[:, 3].cpu()) < 1e-6
+
+
+@pytest.mark.parametrize("mode", ["none", "surface"])
+def test_many_faces_take_the_coarse_bin_path(mode):
+    """From 2048 faces on, tiles scan per-64x64-bin face lists built by a first kernel instead of
+    every face.  5120-face sphere at 80^2 (2x2 bins, the second ragged) against the oracle, and
+    against the same faces rendered in three direct-scan parts (below the face threshold every
+    face is scanned; 1 - alpha is a product over faces, so the parts multiply to the whole)."""
+    import sv3d
+    verts, faces = load_mesh(4)
+    fv = camera_space_faces(verts, faces, 1, seed=41)
+    tex = _textures(mode, 1, faces.shape[0], 2)
+    _compare("ico4_coarse_%s" % mode, fv, tex, 80, False, mode, sigma=3e-5, gamma=1e-2)
+    if mode == "none":
+        x = fv.cuda()
+        prod = torch.ones(1, 192, 192, device="cuda")
+        for lo in range(0, 5120, 1707):
+            part = sv3d.soft_rasterize(x[:, lo:lo + 1707].contiguous(), None, 192, sigma_val=3e-5)
+            prod = prod * (1 - part[:, 3])
+        whole = sv3d.soft_rasterize(x, None, 192, sigma_val=3e-5)
+        assert rel_err((1 - whole[:, 3]).cpu(), prod.cpu()) < 1e-6

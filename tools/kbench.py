@@ -51,6 +51,7 @@ def main():
         h = ctypes.CDLL(os.path.abspath(path))
         vp, sz = ctypes.c_void_p, ctypes.c_size_t
         pp = ctypes.POINTER(L.RasterParams)
+        h.sv3d_raster_sizes.argtypes = [pp, ctypes.POINTER(sz), ctypes.POINTER(sz), ctypes.POINTER(sz)]
         h.sv3d_raster_forward_timed.argtypes = [pp, vp, vp, vp, vp, vp, vp, vp, vp]
         h.sv3d_raster_backward_timed.argtypes = [pp, vp, vp, vp, vp, vp, vp, vp, sz, vp, vp, vp]
         handles.append(h)
@@ -64,7 +65,14 @@ def main():
         S = img * (2 if aa else 1)
         m = {"none": 0, "surface": 1, "vertex": 2, "vertex8": 3}[mode]
         p = L.make_params(B, fv.shape[1], S, 2 if aa else 1, m, T, True, (0, 0, 0), 1, 100, 1e-3, sigma, 1e-10, 1e-4)
-        rec_b, saved_b, ws_b = L.raster_sizes(p)
+        # every library sizes its own buffers (builds may differ in what they keep there): take the
+        # largest requirement over the libraries under test, never the in-tree library's alone
+        rec_b = saved_b = ws_b = 0
+        for h in handles:
+            a, b_, c = ctypes.c_size_t(), ctypes.c_size_t(), ctypes.c_size_t()
+            st = h.sv3d_raster_sizes(ctypes.byref(p), ctypes.byref(a), ctypes.byref(b_), ctypes.byref(c))
+            assert st == 0, st
+            rec_b, saved_b, ws_b = max(rec_b, a.value), max(saved_b, b_.value), max(ws_b, c.value)
         f32 = dict(dtype=torch.float32, device=dev)
         rgba = torch.empty((B, 9 if mode == "vertex8" else 4, img, img), **f32)
         ws_b = max(ws_b, saved_b)                 # older builds want scratch in every mode

@@ -30,7 +30,11 @@ fv, tex, grad = bench.build_inputs(ns, dev, seed=1000)
 S = img * (2 if aa else 1)
 m = {"none": 0, "surface": 1, "vertex": 2}[mode]
 p = L.make_params(B, fv.shape[1], S, 2 if aa else 1, m, T, True, (0, 0, 0), 1, 100, 1e-3, sigma, 1e-10, 1e-4)
-rec_b, saved_b, ws_b = L.raster_sizes(p)
+# buffer sizes from the library under test itself (a build may keep more in them than the in-tree one)
+_a, _b, _c = ctypes.c_size_t(), ctypes.c_size_t(), ctypes.c_size_t()
+lib.sv3d_raster_sizes.argtypes = [ctypes.POINTER(L.RasterParams)] + [ctypes.POINTER(ctypes.c_size_t)] * 3
+assert lib.sv3d_raster_sizes(ctypes.byref(p), ctypes.byref(_a), ctypes.byref(_b), ctypes.byref(_c)) == 0
+rec_b, saved_b, ws_b = max(_a.value, L.raster_sizes(p)[0]), _b.value, _c.value
 f32 = dict(dtype=torch.float32, device=dev)
 rgba = torch.empty((B, 4, img, img), **f32)
 rec, saved = (torch.empty(n // 4, **f32) for n in (rec_b, saved_b))
