@@ -3,7 +3,7 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
 
-Workload (BASELINE.json configs[1]): silhouette-only soft rasterization forward + backward,
+Workload (the headline benchmark configuration): silhouette-only soft rasterization forward + backward,
 batch 8, 256x256, icosphere 642 vertices / 1280 faces, sigma 1e-4, dist_eps 1e-10, inputs
 (camera-space face vertices, incoming gradient) resident in HBM.  One step = one
 sv3d_raster_forward + one sv3d_raster_backward through the C ABI on the batch.  With N > 1

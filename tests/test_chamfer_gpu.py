@@ -131,7 +131,7 @@ def test_bitwise_repeatable():
 
 
 def test_full_size_8192_properties():
-    """BASELINE's 8192 x 8192 clouds: too slow for the scalar oracle in full, so check
+    """The largest benchmark clouds, 8192 x 8192: too slow for the scalar oracle in full, so check
     size-independent properties plus the oracle on a slice of the queries."""
     import sv3d
     rng = np.random.default_rng(8192)

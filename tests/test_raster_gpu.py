@@ -133,7 +133,7 @@ def test_parity_icosphere_reference_constants(mode, aa):
 
 @pytest.mark.parametrize("mode", ["none", "surface", "vertex"])
 def test_parity_sigma_1e4_config(mode):
-    """BASELINE config 2's sigma (1e-4) at 64^2: many overlapping soft fragments per pixel."""
+    """The benchmark configuration's sigma (1e-4) at 64^2: many overlapping soft fragments per pixel."""
     verts, faces = load_mesh(2)
     fv = camera_space_faces(verts, faces, 2, seed=5)
     tex = _textures(mode, 2, faces.shape[0], 2)
@@ -235,7 +235,7 @@ def test_bitwise_repeatable_forward_and_backward():
 
 
 def test_full_size_config2_against_oracle_on_sampled_pixels():
-    """BASELINE config 2: batch 8, 256^2, 642 v / 1280 f, sigma 1e-4, silhouette fwd+bwd.
+    """The headline benchmark configuration: batch 8, 256^2, 642 v / 1280 f, sigma 1e-4, silhouette fwd+bwd.
     The dense oracle is evaluated on 768 sampled pixels per image; the incoming gradient is
     non-zero on exactly those pixels, so the oracle's face gradients are the full ones."""
     import sv3d

@@ -23,7 +23,7 @@ import torch  # noqa: E402
 
 CONFIGS = {
     # name: (batch, image_size, aa, subdivide, sigma, mode, tex_size)
-    "c2": (8, 256, False, 3, 1e-4, "none", 1),               # BASELINE config 2
+    "c2": (8, 256, False, 3, 1e-4, "none", 1),               # the headline benchmark configuration
     "c2b64": (64, 256, False, 3, 1e-4, "none", 1),
     "ref_mask": (64, 256, True, 3, 1e-5, "none", 1),          # reference defaults, Bn = 16*B, B = 4
     "ref_rgb": (64, 256, True, 3, 1e-5, "surface", 6),
