@@ -17,6 +17,7 @@
 #include <math.h>
 #include <stdint.h>
 
+#include "bucket_sort.h"
 #include "sv3d_hip.h"
 
 namespace {
@@ -226,6 +227,68 @@ __global__ __launch_bounds__(kThreads) void chamfer_grad_kernel(
     }
 }
 
+// The same backward with the scattered term read from buckets instead of a scan: one
+// 1024-thread workgroup per (direction, batch element) sorts the other cloud's points j by their
+// nearest-neighbour index idx_other[j] (LDS counting sort) and every own point i adds its bucket
+// in ascending j -- O(N + M) instead of O(N M), the sum order of the scan form, no atomics on
+// floats.  Dynamic LDS: (2 n_own + n_other) ints.
+__global__ __launch_bounds__(sv3d_dev::kSortThreads) void chamfer_grad_sorted_kernel(
+    const float *__restrict__ xyz1, const float *__restrict__ xyz2, int N, int M,
+    const float *__restrict__ gd1, const float *__restrict__ gd2,
+    const int32_t *__restrict__ idx1, const int32_t *__restrict__ idx2,
+    float *__restrict__ g1, float *__restrict__ g2)
+{
+    extern __shared__ int smem[];
+    __shared__ int s_wave[sv3d_dev::kSortThreads / 64];
+    const int b = blockIdx.y;
+    const bool dir1 = blockIdx.x == 1;
+    const int n_own = dir1 ? M : N;
+    const int n_oth = dir1 ? N : M;
+    const float *own = dir1 ? xyz2 + (size_t)b * M * 3 : xyz1 + (size_t)b * N * 3;
+    const float *oth = dir1 ? xyz1 + (size_t)b * N * 3 : xyz2 + (size_t)b * M * 3;
+    const float *gd_own = dir1 ? gd2 : gd1;
+    const float *gd_oth = dir1 ? gd1 : gd2;
+    const int32_t *idx_own = dir1 ? idx2 + (size_t)b * M : idx1 + (size_t)b * N;
+    const int32_t *idx_oth = dir1 ? idx1 + (size_t)b * N : idx2 + (size_t)b * M;
+    float *gout = dir1 ? g2 : g1;
+    if (gout == nullptr) return;                         // uniform over the block
+    gout += (size_t)b * n_own * 3;
+    int *fill = smem, *start = smem + n_own, *bucket = smem + 2 * n_own;
+    if (gd_oth != nullptr) sv3d_dev::build_buckets(idx_oth, n_own, n_oth, fill, start, bucket, s_wave);
+    for (int i = threadIdx.x; i < n_own; i += sv3d_dev::kSortThreads) {
+        const float ox = own[3 * i], oy = own[3 * i + 1], oz = own[3 * i + 2];
+        float ax = 0.f, ay = 0.f, az = 0.f;
+        if (gd_own != nullptr) {
+            const int j = idx_own[i];
+            const float g = 2.f * gd_own[(size_t)b * n_own + i];
+            ax = g * (ox - oth[3 * j]);
+            ay = g * (oy - oth[3 * j + 1]);
+            az = g * (oz - oth[3 * j + 2]);
+        }
+        if (gd_oth != nullptr) {
+            const int s0 = start[i], s1 = fill[i];
+            int last = -1;
+            for (int k = s0; k < s1; ++k) {
+                last = sv3d_dev::next_slot(bucket, s0, s1, last);
+                // an index outside the own cloud was clamped into a bucket by the sort; the scan
+                // form never matches it, so it is skipped here as well
+                if (idx_oth[last] != i) continue;
+                const float g = 2.f * gd_oth[(size_t)b * n_oth + last];
+                const float *o = oth + 3 * (size_t)last;
+                ax -= g * (o[0] - ox);
+                ay -= g * (o[1] - oy);
+                az -= g * (o[2] - oz);
+            }
+        }
+        gout[3 * i] = ax;
+        gout[3 * i + 1] = ay;
+        gout[3 * i + 2] = az;
+    }
+}
+
+constexpr size_t kSortLdsDefault = 64 * 1024;
+constexpr size_t kSortLdsMax = 150 * 1024;
+
 inline int launch_status()
 {
     return hipGetLastError() == hipSuccess ? SV3D_OK : SV3D_ERR_LAUNCH;
@@ -267,6 +330,23 @@ extern "C" int sv3d_chamfer_backward(const float *xyz1, const float *xyz2, int32
     if (B > 65535) return SV3D_ERR_UNSUPPORTED;
     if (!grad_xyz1 && !grad_xyz2) return SV3D_OK;
     hipStream_t s = static_cast<hipStream_t>(stream);
+    // The scattered term (the gradient a cloud receives through the OTHER cloud's distances) is
+    // what costs: with it present and tables that fit the LDS, the sorted form; else the scan form
+    // (whose scan loop is skipped when that term is absent, as in the reference's use).
+    const size_t lds = ((size_t)2 * (N > M ? N : M) + (size_t)(N > M ? N : M)) * sizeof(int);
+    const bool scattered = (grad_xyz1 && grad_dist2) || (grad_xyz2 && grad_dist1);
+    bool sorted = scattered && lds <= kSortLdsMax;
+    if (sorted && lds > kSortLdsDefault &&
+        hipFuncSetAttribute(reinterpret_cast<const void *>(&chamfer_grad_sorted_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+        (void)hipGetLastError();
+        sorted = false;
+    }
+    if (sorted) {
+        hipLaunchKernelGGL(chamfer_grad_sorted_kernel, dim3(2, B), dim3(sv3d_dev::kSortThreads), lds, s, xyz1,
+                           xyz2, N, M, grad_dist1, grad_dist2, idx1, idx2, grad_xyz1, grad_xyz2);
+        return launch_status();
+    }
     const int b0 = (N + kThreads - 1) / kThreads, b1 = (M + kThreads - 1) / kThreads;
     dim3 grid(b0 + b1, B), block(kThreads);
     hipLaunchKernelGGL(chamfer_grad_kernel, grid, block, 0, s, xyz1, xyz2, N, M, grad_dist1,

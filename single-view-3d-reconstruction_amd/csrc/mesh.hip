@@ -7,6 +7,7 @@
 
 #include <limits.h>
 
+#include "bucket_sort.h"
 #include "camera.h"
 #include "sv3d_hip.h"
 
@@ -132,7 +133,9 @@ __device__ inline void camera_backward(const Camera &c, float X, float Y, float 
     acc[6] += s2 * (-gX * c.uz + gu * Z + uX * gz + c.w * kz);
 }
 
-constexpr int kSortThreads = 1024;
+using sv3d_dev::build_buckets;
+using sv3d_dev::kSortThreads;
+using sv3d_dev::next_slot;
 
 // Sum of 7 per-thread values over a 1024-thread block in a fixed order; thread i < 7 stores
 // total i to dst[i].
@@ -153,54 +156,6 @@ __device__ inline void block_sum7(float acc[7], float (*s_red)[8], float *dst)
         for (int w = 0; w < kSortThreads / 64; ++w) t += s_red[w][threadIdx.x];
         dst[threadIdx.x] = t;
     }
-}
-
-// LDS counting sort of an image's 3F corner slots by vertex: on return bucket[start[v] .. fill[v])
-// holds the slots that reference vertex v, in arbitrary order.  All kSortThreads threads call it.
-__device__ inline void build_buckets(const int32_t *__restrict__ fb, int V, int nslots, int *fill,
-                                     int *start, int *bucket, int *s_wave)
-{
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int v = tid; v < V; v += kSortThreads) fill[v] = 0;
-    __syncthreads();
-    for (int i = tid; i < nslots; i += kSortThreads) atomicAdd(&fill[min(max(fb[i], 0), V - 1)], 1);
-    __syncthreads();
-    // exclusive scan of the counts; thread t owns entries [t*per, (t+1)*per)
-    const int per = (V + kSortThreads - 1) / kSortThreads;
-    const int lo = min(tid * per, V), hi = min(lo + per, V);
-    int local = 0;
-    for (int v = lo; v < hi; ++v) local += fill[v];
-    int incl = local;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const int n = __shfl_up(incl, d);
-        if (lane >= d) incl += n;
-    }
-    if (lane == 63) s_wave[wave] = incl;
-    __syncthreads();
-    int run = incl - local;
-    for (int w = 0; w < wave; ++w) run += s_wave[w];
-    for (int v = lo; v < hi; ++v) {
-        const int c = fill[v];
-        start[v] = run;
-        fill[v] = run;
-        run += c;
-    }
-    __syncthreads();
-    for (int i = tid; i < nslots; i += kSortThreads) bucket[atomicAdd(&fill[min(max(fb[i], 0), V - 1)], 1)] = i;
-    __syncthreads();
-}
-
-// Next slot of bucket [s0, s1) above `last`, so that a bucket is walked in ascending slot order
-// whatever order the sort left it in.
-__device__ inline int next_slot(const int *bucket, int s0, int s1, int last)
-{
-    int m = INT_MAX;
-    for (int j = s0; j < s1; ++j) {
-        const int s = bucket[j];
-        m = (s > last && s < m) ? s : m;
-    }
-    return m;
 }
 
 // Backward of the gather (and, with PROJECT, of the camera in front of it): one 1024-thread

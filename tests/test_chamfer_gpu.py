@@ -90,6 +90,30 @@ def test_backward_matches_oracle(use1, use2):
     assert rel_err(tb.grad.cpu(), torch.from_numpy(w2)) < GRAD_RTOL
 
 
+@pytest.mark.parametrize("N,M", [(8192, 8192),      # sorted form, LDS tables above 64 KB
+                                 (700, 14000)])     # tables beyond the LDS: scan form
+def test_backward_both_sides_large_clouds(N, M):
+    import sv3d
+    rng = np.random.default_rng(21)
+    a = rng.standard_normal((2, N, 3)).astype(np.float32)
+    b = rng.standard_normal((2, M, 3)).astype(np.float32)
+    b[:, 100:400] = b[:, 7:8]                      # one long bucket
+    gd1 = rng.standard_normal((2, N)).astype(np.float32)
+    gd2 = rng.standard_normal((2, M)).astype(np.float32)
+    ta = torch.from_numpy(a).cuda().requires_grad_(True)
+    tb = torch.from_numpy(b).cuda().requires_grad_(True)
+    grads = []
+    for _ in range(2):
+        ta.grad = tb.grad = None
+        d1, d2, i1, i2 = sv3d.chamfer_nn(ta, tb)
+        ((d1 * torch.from_numpy(gd1).cuda()).sum() + (d2 * torch.from_numpy(gd2).cuda()).sum()).backward()
+        grads.append((ta.grad.clone(), tb.grad.clone()))
+    assert torch.equal(grads[0][0], grads[1][0]) and torch.equal(grads[0][1], grads[1][1])
+    w1, w2 = chamfer_oracle.backward_c(a, b, gd1, gd2, i1.cpu().numpy(), i2.cpu().numpy())
+    assert rel_err(grads[0][0].cpu(), torch.from_numpy(w1)) < GRAD_RTOL
+    assert rel_err(grads[0][1].cpu(), torch.from_numpy(w2)) < GRAD_RTOL
+
+
 def test_reference_usage_only_dist2_and_detached_first_cloud():
     """loss_utils.py:75-88 keeps dist2.mean(); main.py:525 detaches the first cloud."""
     from nnutils import loss_utils
