@@ -200,6 +200,37 @@ int sv3d_render_forward(const sv3d_raster_params *p, const sv3d_mesh_input *mesh
                         const float *textures, float *face_vertices_out, float *rgba_out,
                         void *face_rec, void *pixel_saved, void *stream);
 
+/* ---- mesh regularisers of the training step ------------------------------------------------
+ * Each call returns the per-mesh loss [B] and, when grad_vertices is not NULL, d loss[b] /
+ * d vertices[b] as [B,V,3] in the same launch; the caller scales that by the incoming gradient.
+ * Index arrays are shared by the batch; entries outside their range are clamped.             */
+
+/* `sr.LaplacianLoss(vertex, faces)(x)` as built at main.py:202 and called at main.py:515: the
+ * uniform graph Laplacian with rows divided by the vertex degree,
+ *   loss[b] = sum_v | x[b,v] - mean of x[b,n] over the neighbours n of v |^2.
+ * The neighbour lists are CSR: nbr[row_start[v] .. row_start[v+1]), without v itself; the
+ * relation must be symmetric (it is for the edges of a face list).  The reference holds the
+ * operator as a dense V x V matrix.  SV3D_ERR_UNSUPPORTED when 16 V bytes exceed 150 KB of LDS. */
+int sv3d_laplacian_loss(const float *vertices, const int32_t *row_start, const int32_t *nbr, int32_t B,
+                        int32_t V, float *loss, float *grad_vertices, void *stream);
+
+/* `sr.FlattenLoss(faces)(x)` (main.py:203,516): over the E interior edges, quads[e] =
+ * (v0, v1, v2, v3) with (v0,v1) the edge and v2, v3 the opposite vertices of its two faces,
+ *   loss[b] = sum_e (cos_e + 1)^2,  cos_e between the two in-face altitudes onto the edge,
+ * with the eps placement of the upstream module (eps = 1e-6 there).  inc[inc_start[v] ..
+ * inc_start[v+1]) lists, ascending, the entries 4 e + k for which quads[e][k] == v; it is only
+ * read when grad_vertices is not NULL.                                                        */
+int sv3d_flatten_loss(const float *vertices, const int32_t *quads, const int32_t *inc_start,
+                      const int32_t *inc, int32_t B, int32_t V, int32_t E, float eps, float *loss,
+                      float *grad_vertices, void *stream);
+
+/* y[b,v,:] = sum_k values[vb,k] * x[b, col[k], :] over the CSR row v (k ascending): the product
+ * of `Laplacian.forward` / `.backward`, nnutils/laplacian.py:63-103 (scipy on the host there,
+ * with a device -> host -> device copy per call).  x, y [B,V,3]; values [values_batch, nnz] with
+ * values_batch = B, or 1 for weights shared by the batch.                                     */
+int sv3d_mesh_spmv(const float *values, const int32_t *row_start, const int32_t *col, const float *x,
+                   int32_t B, int32_t V, int32_t nnz, int32_t values_batch, float *y, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,13 +1,27 @@
 """Mesh regularisers with the constructor / call contract of `sr.LaplacianLoss(vertex, faces)`
 and `sr.FlattenLoss(faces)` as the reference builds them at main.py:202-203 and calls them at
-main.py:515-516.  Plain torch: these are O(V) / O(E) terms next to the rasterizer."""
+main.py:515-516.
+
+Each call is one HIP launch that returns the loss and its vertex gradient (sv3d/meshreg.py): the
+uniform Laplacian as a sparse neighbour stencil instead of the upstream dense V x V matmul, the
+flatten loss without its ~40 elementwise launches.  GPU tensors only; CPU tensors raise.
+"""
 import numpy as np
 import torch
 import torch.nn as nn
 
+from sv3d import meshreg
+
+# the fused Laplacian kernel keeps 4 V floats in the LDS (150 KB at most)
+_FUSED_MAX_VERTICES = 150 * 1024 // 16
+
 
 def _np(x):
     return x.detach().cpu().numpy() if torch.is_tensor(x) else np.asarray(x)
+
+
+def _reduce(out, batch, average):
+    return out.sum() / batch if average else out
 
 
 class LaplacianLoss(nn.Module):
@@ -19,19 +33,35 @@ class LaplacianLoss(nn.Module):
         self.nv = int(vertex.shape[0])
         self.nf = int(faces.shape[0])
         self.average = average
-        f = _np(faces).astype(np.int64)
-        lap = np.zeros((self.nv, self.nv), dtype=np.float32)
-        for a, b in ((0, 1), (1, 0), (1, 2), (2, 1), (2, 0), (0, 2)):
-            lap[f[:, a], f[:, b]] = -1
-        idx = np.arange(self.nv)
-        lap[idx, idx] = -lap.sum(1)
-        lap /= np.maximum(lap[idx, idx], 1e-12)[:, None]
-        self.register_buffer('laplacian', torch.from_numpy(lap))
+        row_start, nbr = meshreg.neighbour_csr(_np(faces), self.nv)
+        self.register_buffer('row_start', torch.from_numpy(row_start))
+        self.register_buffer('nbr', torch.from_numpy(nbr))
+        if self.nv > _FUSED_MAX_VERTICES:
+            # y = L x through the CSR product, L = I - D^-1 A and its transpose
+            deg = np.diff(row_start).astype(np.int64)
+            rows = np.repeat(np.arange(self.nv), deg)
+            live = np.flatnonzero(deg > 0)
+            r = np.concatenate([rows, live])
+            c = np.concatenate([nbr.astype(np.int64), live])
+            w = np.concatenate([-1.0 / deg[rows], np.ones(live.size)]).astype(np.float32)
+            for name, (rr, cc) in (('fwd', (r, c)), ('bwd', (c, r))):
+                start, col, slot = meshreg.csr_from_coo(rr, cc, self.nv)
+                val = np.zeros(col.size, np.float32)
+                val[slot] = w
+                self.register_buffer(name + '_val', torch.from_numpy(val)[None])
+                self.register_buffer(name + '_start', torch.from_numpy(start))
+                self.register_buffer(name + '_col', torch.from_numpy(col))
 
     def forward(self, x):
-        y = torch.matmul(self.laplacian, x)
-        out = y.pow(2).sum(tuple(range(1, y.dim())))
-        return out.sum() / x.size(0) if self.average else out
+        if x.dim() != 3 or x.shape[1] != self.nv:
+            raise ValueError("expected vertices [B,%d,3], got %s" % (self.nv, tuple(x.shape)))
+        if self.nv > _FUSED_MAX_VERTICES:
+            y = meshreg.mesh_spmv(x, (self.fwd_val, self.fwd_start, self.fwd_col),
+                                  (self.bwd_val, self.bwd_start, self.bwd_col))
+            out = y.pow(2).sum((1, 2))
+        else:
+            out = meshreg.laplacian_loss(x, self.row_start, self.nbr)
+        return _reduce(out, x.size(0), self.average)
 
 
 class FlattenLoss(nn.Module):
@@ -42,32 +72,24 @@ class FlattenLoss(nn.Module):
         super(FlattenLoss, self).__init__()
         self.nf = int(faces.shape[0])
         self.average = average
-        f = _np(faces).astype(np.int64)
-        opposite = {}
-        for tri in f:
-            for k in range(3):
-                a, b, c = int(tri[k]), int(tri[(k + 1) % 3]), int(tri[(k + 2) % 3])
-                opposite.setdefault((min(a, b), max(a, b)), []).append(c)
-        quads = [(e[0], e[1], o[0], o[1]) for e, o in sorted(opposite.items()) if len(o) == 2]
-        q = np.asarray(quads, dtype=np.int64).reshape(-1, 4)
+        f = _np(faces)
+        self.nv = int(f.max()) + 1
+        q = meshreg.edge_quads(f)
         for i, name in enumerate(('v0s', 'v1s', 'v2s', 'v3s')):
             self.register_buffer(name, torch.from_numpy(q[:, i].copy()))
+        inc_start, inc = meshreg.incidence_csr(q, self.nv)
+        self.register_buffer('quads', torch.from_numpy(q.astype(np.int32)))
+        self.register_buffer('inc_start', torch.from_numpy(inc_start))
+        self.register_buffer('inc', torch.from_numpy(inc))
 
     def forward(self, vertices, eps=1e-6):
-        v0, v1 = vertices[:, self.v0s], vertices[:, self.v1s]
-        a = v1 - v0
-        al2 = a.pow(2).sum(-1)
-
-        def altitude(vk):
-            b = vk - v0
-            bl1 = (b.pow(2).sum(-1) + eps).sqrt()
-            ab = (a * b).sum(-1)
-            cos = ab / ((al2 + eps).sqrt() * bl1 + eps)
-            sin = (1 - cos.pow(2) + eps).sqrt()
-            return b - a * (ab / (al2 + eps))[..., None], bl1 * sin
-
-        c1, l1 = altitude(vertices[:, self.v2s])
-        c2, l2 = altitude(vertices[:, self.v3s])
-        cos = (c1 * c2).sum(-1) / (l1 * l2 + eps)
-        out = (cos + 1).pow(2).sum(tuple(range(1, cos.dim())))
-        return out.sum() / vertices.size(0) if self.average else out
+        nv = vertices.shape[1]
+        if vertices.dim() != 3 or nv < self.nv:
+            raise ValueError("expected vertices [B,>=%d,3], got %s" % (self.nv, tuple(vertices.shape)))
+        if nv != self.nv:                          # vertices beyond the last one a face uses
+            pad = self.inc_start[-1:].expand(nv - self.nv)
+            inc_start = torch.cat([self.inc_start, pad])
+        else:
+            inc_start = self.inc_start
+        out = meshreg.flatten_loss(vertices, self.quads, inc_start, self.inc, eps)
+        return _reduce(out, vertices.size(0), self.average)

@@ -19,6 +19,7 @@ EXPORTS = (
     "sv3d_face_gather", "sv3d_face_scatter",
     "sv3d_project_gather", "sv3d_project_scatter", "sv3d_render_forward",
     "sv3d_face_gather_n", "sv3d_face_scatter_n",
+    "sv3d_laplacian_loss", "sv3d_flatten_loss", "sv3d_mesh_spmv",
 )
 
 
@@ -79,6 +80,9 @@ def lib():
         L.sv3d_face_scatter.argtypes = [vp, vp, i32, i32, i32, i32, f3, vp, vp]
         L.sv3d_face_gather_n.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp, vp]
         L.sv3d_face_scatter_n.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp, vp]
+        L.sv3d_laplacian_loss.argtypes = [vp, vp, vp, i32, i32, vp, vp, vp]
+        L.sv3d_flatten_loss.argtypes = [vp, vp, vp, vp, i32, i32, i32, ctypes.c_float, vp, vp, vp]
+        L.sv3d_mesh_spmv.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, vp, vp]
         mp = ctypes.POINTER(MeshInput)
         L.sv3d_project_gather.argtypes = [mp, i32, i32, vp, vp]
         L.sv3d_project_scatter.argtypes = [mp, i32, i32, vp, vp, vp, vp]

@@ -1,0 +1,237 @@
+"""Mesh regularisers: HIP kernels behind `sr.LaplacianLoss`, `sr.FlattenLoss` (main.py:202-203,
+515-516) and the cotangent Laplacian (nnutils/laplacian.py, loss_utils.py:565-583) against the CPU
+restatement in oracle/meshreg_oracle.py (fp64).  Parity unpinned: the oracle restates the
+upstream definitions; no output of the reference itself is available.
+
+Tolerances: losses and gradients 1e-5 of the largest reference value (fp32 kernels against an
+fp64 oracle; the fp32 rounding floor of the same formulas is reported by the oracle in fp32).
+"""
+import numpy as np
+import pytest
+import torch
+
+from helpers import load_mesh, random_vertices, rel_err
+from oracle import meshreg_oracle as mo
+
+TOL = 1e-5
+
+
+def _oracle_loss_and_grad(fn, verts, faces, weights):
+    x = verts.double().requires_grad_(True)
+    loss = fn(x, faces.numpy())
+    (loss * weights.double()).sum().backward()
+    return loss.detach(), x.grad
+
+
+# ------------------------------------------------------------------------------- CPU: host tables
+def test_host_tables_match_the_oracle_topology():
+    from sv3d import meshreg
+    verts, faces = load_mesh(3)
+    V = verts.shape[0]
+    row_start, nbr = meshreg.neighbour_csr(faces, V)
+    lap = mo.uniform_laplacian_matrix(V, faces.numpy())
+    assert row_start[-1] == nbr.size == int((lap < 0).sum())
+    for v in (0, 1, 17, V - 1):
+        assert list(nbr[row_start[v]:row_start[v + 1]]) == list(np.flatnonzero(lap[v] < 0))
+    q = meshreg.edge_quads(faces)
+    assert np.array_equal(q, mo.flatten_quads(faces.numpy()))
+    assert q.shape == (1920, 4)                            # closed icosphere: E = 3 F / 2
+    inc_start, inc = meshreg.incidence_csr(q, V)
+    assert inc.size == 4 * q.shape[0] and inc_start[-1] == inc.size
+    for v in (0, 5, V - 1):
+        ent = inc[inc_start[v]:inc_start[v + 1]]
+        assert np.all(np.diff(ent) > 0) and np.all(q.reshape(-1)[ent] == v)
+    start, col, slot = meshreg.csr_from_coo([2, 0, 2, 0], [1, 3, 1, 0], 3)
+    assert list(start) == [0, 2, 2, 3] and list(col) == [0, 3, 1] and list(slot) == [2, 1, 2, 0]
+
+
+def test_cotangent_oracle_properties():
+    """Closed forms: an equilateral triangle has weight cot(60 deg)/2 on every edge; L is symmetric
+    and annihilates constants; on a regular mesh L x points along the normal."""
+    V = np.array([[[0.0, 0, 0], [1, 0, 0], [0.5, np.sqrt(3) / 2, 0]]])
+    F = np.array([[[0, 1, 2]]])
+    assert np.allclose(mo.cotangent(V, F), 0.5 / np.sqrt(3), atol=1e-12)
+    verts, faces = load_mesh(3)
+    X = verts.double().numpy()[None]
+    Lm = mo.cotangent_laplacian(X, faces.numpy().astype(np.int64)[None])
+    assert np.allclose(Lm, Lm.transpose(0, 2, 1)) and np.abs(Lm.sum(2)).max() < 1e-9
+    Lx = mo.laplacian_apply(Lm, X)[0]
+    n = X[0] / np.linalg.norm(X[0], axis=1, keepdims=True)
+    cosang = (Lx * n).sum(1) / np.linalg.norm(Lx, axis=1)
+    assert np.all(cosang < -0.999)                        # mean-curvature normal of a sphere, inward
+
+
+def test_cpu_tensors_raise():
+    import soft_renderer as sr
+    verts, faces = load_mesh(3)
+    with pytest.raises(RuntimeError):
+        sr.LaplacianLoss(verts, faces)(verts[None])
+    with pytest.raises(RuntimeError):
+        sr.FlattenLoss(faces)(verts[None])
+
+
+# ------------------------------------------------------------------------------------- GPU parity
+@pytest.mark.gpu
+@pytest.mark.parametrize("sub,B", [(3, 5), (4, 2)])
+def test_uniform_laplacian_loss_and_gradient(sub, B):
+    import soft_renderer as sr
+    verts, faces = load_mesh(sub)
+    x = random_vertices(verts, B, seed=3, jitter=0.05)
+    w = torch.linspace(0.5, 2.0, B)
+    want, want_g = _oracle_loss_and_grad(mo.laplacian_loss, x, faces, w)
+    mod = sr.LaplacianLoss(verts, faces).cuda()
+    xg = x.cuda().requires_grad_(True)
+    got = mod(xg)
+    (got * w.cuda()).sum().backward()
+    assert got.shape == (B,)
+    assert rel_err(got.cpu(), want) < TOL
+    assert rel_err(xg.grad.cpu(), want_g) < TOL
+    avg = sr.LaplacianLoss(verts, faces, average=True).cuda()(x.cuda())
+    assert avg.dim() == 0 and abs(avg.item() - want.sum().item() / B) < TOL * want.sum().item()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sub,B,jitter", [(3, 5, 0.02), (4, 2, 0.01), (3, 4, 0.05)])
+def test_flatten_loss_and_gradient(sub, B, jitter):
+    """jitter 0.02 on the 642-vertex sphere is the benchmark's deformation.  The 0.05 case folds
+    faces over (1 - cos^2 cancels, gradients reach 1e3): there fp32 evaluation of the defining
+    formula is itself 1e-4 from fp64, so the bound is that rounding floor, measured by running the
+    oracle in fp32."""
+    import soft_renderer as sr
+    verts, faces = load_mesh(sub)
+    x = random_vertices(verts, B, seed=4, jitter=jitter)
+    w = torch.linspace(2.0, 0.5, B)
+    want, want_g = _oracle_loss_and_grad(mo.flatten_loss, x, faces, w)
+    x32 = x.clone().requires_grad_(True)
+    (mo.flatten_loss(x32, faces.numpy()) * w).sum().backward()
+    tol = max(TOL, rel_err(x32.grad, want_g))
+    mod = sr.FlattenLoss(faces).cuda()
+    xg = x.cuda().requires_grad_(True)
+    got = mod(xg)
+    (got * w.cuda()).sum().backward()
+    assert got.shape == (B,)
+    assert rel_err(got.cpu(), want) < TOL
+    assert rel_err(xg.grad.cpu(), want_g) < tol, (rel_err(xg.grad.cpu(), want_g), tol)
+    if jitter <= 0.02:
+        assert tol == TOL
+
+
+@pytest.mark.gpu
+def test_flatten_degenerate_and_open_meshes():
+    """A flat open strip: no interior edge is bent (loss 0 up to eps terms); a zero-length edge
+    stays finite through the eps terms as in the oracle."""
+    import soft_renderer as sr
+    faces = torch.tensor([[0, 1, 2], [2, 1, 3], [2, 3, 4], [4, 3, 5]], dtype=torch.int32)
+    flat = torch.tensor([[0.0, 0, 0], [0, 1, 0], [1, 0, 0], [1, 1, 0], [2, 0, 0], [2, 1, 0]])
+    x = torch.stack([flat, flat.clone(), flat.clone()])
+    x[1, 3, 2] = 0.7                                        # bend
+    x[2, 3] = x[2, 2]                                       # collapse the edge (2,3)
+    want, want_g = _oracle_loss_and_grad(mo.flatten_loss, x, faces, torch.ones(3))
+    xg = x.cuda().requires_grad_(True)
+    got = sr.FlattenLoss(faces).cuda()(xg)
+    got.sum().backward()
+    assert torch.isfinite(got).all() and torch.isfinite(xg.grad).all()
+    assert float(got[0]) < 1e-4
+    # fp32 against fp64 next to a collapsed edge: looser
+    assert rel_err(got.cpu(), want) < 1e-4
+    assert rel_err(xg.grad[:2].cpu(), want_g[:2]) < 1e-4
+
+
+@pytest.mark.gpu
+def test_regularisers_bitwise_repeatable_and_match_gradcheck_direction():
+    import soft_renderer as sr
+    verts, faces = load_mesh(3)
+    x = random_vertices(verts, 3, seed=8, jitter=0.05).cuda()
+    lap, flat = sr.LaplacianLoss(verts, faces).cuda(), sr.FlattenLoss(faces).cuda()
+    outs = []
+    for _ in range(2):
+        xg = x.clone().requires_grad_(True)
+        l1, l2 = lap(xg), flat(xg)
+        (l1.sum() + l2.sum()).backward()
+        outs.append((l1, l2, xg.grad.clone()))
+    assert all(torch.equal(a, b) for a, b in zip(*outs))
+    # a small step against the gradient lowers both losses
+    step = x - 1e-3 * outs[0][2]
+    assert (lap(step) + flat(step)).sum() < (outs[0][0] + outs[0][1]).sum()
+
+
+@pytest.mark.gpu
+def test_large_mesh_uses_the_csr_product():
+    """Above the fused kernel's LDS limit the uniform Laplacian goes through the CSR product and
+    its transpose; checked against the same oracle on a subdivided mesh with 10242 vertices."""
+    import soft_renderer as sr
+    from soft_renderer import losses
+    v, f = load_mesh(4)
+    # one 4-to-1 subdivision on the host
+    f64 = f.numpy().astype(np.int64)
+    edges = {}
+    pts = [p for p in v.numpy()]
+
+    def mid(a, b):
+        k = (min(a, b), max(a, b))
+        if k not in edges:
+            edges[k] = len(pts)
+            pts.append((pts[a] + pts[b]) / 2)
+        return edges[k]
+
+    nf = []
+    for a, b, c in f64:
+        ab, bc, ca = mid(a, b), mid(b, c), mid(c, a)
+        nf += [(a, ab, ca), (ab, b, bc), (ca, bc, c), (ab, bc, ca)]
+    verts = torch.from_numpy(np.asarray(pts, np.float32))
+    faces = torch.from_numpy(np.asarray(nf, np.int32))
+    assert verts.shape[0] == 10242 > losses._FUSED_MAX_VERTICES
+    x = random_vertices(verts, 2, seed=5, jitter=0.01)
+    want, want_g = _oracle_loss_and_grad(mo.laplacian_loss, x, faces, torch.ones(2))
+    xg = x.cuda().requires_grad_(True)
+    got = sr.LaplacianLoss(verts, faces).cuda()(xg)
+    got.sum().backward()
+    assert rel_err(got.cpu(), want) < TOL
+    assert rel_err(xg.grad.cpu(), want_g) < TOL
+
+
+@pytest.mark.gpu
+def test_cotangent_laplacian_module_and_loss():
+    """nnutils/laplacian.py: L from the first call's vertices, reused afterwards; backward is the
+    same product (L symmetric); loss_utils.LaplacianLoss = mean |L x|_2."""
+    from nnutils import laplacian, loss_utils
+    verts, faces = load_mesh(3)
+    B = 3
+    rng = np.random.default_rng(42)
+    V0 = (verts.numpy()[None] * np.array([1.0, 0.8, 1.2]) + 0.02 * rng.standard_normal((B, 642, 3))).astype(np.float32)
+    X = (V0 + 0.05 * rng.standard_normal(V0.shape)).astype(np.float32)
+    G = rng.standard_normal(V0.shape).astype(np.float32)
+    F = np.broadcast_to(faces.numpy().astype(np.int64)[None], (B, 1280, 3)).copy()
+
+    C = laplacian.cotangent(torch.from_numpy(V0).cuda(), torch.from_numpy(F).cuda())
+    assert rel_err(C.cpu(), torch.from_numpy(mo.cotangent(V0.astype(np.float64), F))) < TOL
+
+    Lm = mo.cotangent_laplacian(V0.astype(np.float64), F)
+    module = laplacian.LaplacianModule(torch.from_numpy(F).cuda())
+    lx0 = module(torch.from_numpy(V0).cuda())
+    assert rel_err(lx0.cpu(), torch.from_numpy(mo.laplacian_apply(Lm, V0.astype(np.float64)))) < TOL
+    x = torch.from_numpy(X).cuda().requires_grad_(True)
+    lx = module(x)                                          # same L, other vertices
+    lx.backward(torch.from_numpy(G).cuda())
+    assert rel_err(lx.cpu(), torch.from_numpy(mo.laplacian_apply(Lm, X.astype(np.float64)))) < TOL
+    assert rel_err(x.grad.cpu(), torch.from_numpy(mo.laplacian_apply(Lm, G.astype(np.float64)))) < TOL
+    with pytest.raises(ValueError):
+        module(x[:2])
+
+    loss_fn = loss_utils.LaplacianLoss(torch.from_numpy(F).cuda())
+    loss = loss_fn(torch.from_numpy(V0).cuda())
+    want = mo.cotangent_laplacian_loss(Lm, V0.astype(np.float64))
+    assert loss.dim() == 0 and abs(loss.item() - want) < TOL * want
+
+
+@pytest.mark.gpu
+def test_regulariser_ops_trace_under_fake_tensors():
+    from torch._subclasses.fake_tensor import FakeTensorMode
+    from sv3d import meshreg
+    verts, faces = load_mesh(3)
+    rs, nb = meshreg.neighbour_csr(faces, 642)
+    with FakeTensorMode():
+        x = torch.empty(2, 642, 3, device="cuda")
+        loss, grad = meshreg.laplacian_loss_op(x, torch.empty(643, dtype=torch.int32, device="cuda"),
+                                               torch.empty(nb.size, dtype=torch.int32, device="cuda"))
+        assert loss.shape == (2,) and grad.shape == (2, 642, 3)

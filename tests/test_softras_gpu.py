@@ -117,17 +117,15 @@ def test_soft_renderer_object_model():
 def test_mesh_regularisers_and_obj_roundtrip(tmp_path):
     import soft_renderer as sr
     verts, faces = load_mesh(2)
-    lap = sr.LaplacianLoss(verts, faces)
-    flat = sr.FlattenLoss(faces)
-    x = verts[None].clone()
+    lap = sr.LaplacianLoss(verts, faces).cuda()
+    flat = sr.FlattenLoss(faces).cuda()
+    x = verts[None].clone().cuda()
     # a sphere is locally flat-ish and regular: both losses are small and grow under noise
     l0, f0 = float(lap(x)), float(flat(x))
-    xn = x + 0.05 * torch.randn(x.shape, generator=torch.Generator().manual_seed(0))
+    xn = x + 0.05 * torch.randn(x.shape, generator=torch.Generator().manual_seed(0)).cuda()
     assert float(lap(xn)) > l0 and float(flat(xn)) > f0
     assert flat.v0s.shape[0] == 3 * faces.shape[0] // 2          # closed manifold: E = 3F/2
-    L = lap.laplacian
-    assert torch.allclose(L.sum(1), torch.zeros(L.shape[0]), atol=1e-5)
-    assert torch.allclose(torch.diagonal(L), torch.ones(L.shape[0]))
+    assert lap.nbr.numel() == 2 * flat.v0s.shape[0]              # every edge seen from both ends
     path = os.path.join(str(tmp_path), "m.obj")
     sr.save_obj(path, verts, faces)
     v2, f2 = sr.load_obj(path)
