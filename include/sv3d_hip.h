@@ -231,6 +231,36 @@ int sv3d_flatten_loss(const float *vertices, const int32_t *quads, const int32_t
 int sv3d_mesh_spmv(const float *values, const int32_t *row_start, const int32_t *col, const float *x,
                    int32_t B, int32_t V, int32_t nnz, int32_t values_batch, float *y, void *stream);
 
+/* ---- texture path either side of the rasterizer -------------------------------------------- */
+
+/* `geom_utils.sample_textures(texture_flow, images)`, nnutils/geom_utils.py:11-26, and the same
+ * sampling of a distance map in `texture_dt_loss_per_instance`, nnutils/loss_utils.py:242-256:
+ * `grid_sample(images, flow, align_corners=True)` (bilinear, zero padding) followed by the permute
+ * to channels-last, written directly as the rasterizer's texel layout:
+ *   images [B,C,H,W], C <= 4;  flow [B,N,2] in [-1,1] (x, y), N = F*T*T;  out [B,N,C].           */
+int sv3d_texture_sample(const float *images, const float *flow, int32_t B, int32_t C, int32_t H,
+                        int32_t W, int32_t N, float *out, void *stream);
+
+/* Its backward to the flow: grad_out [B,N,C] -> grad_flow [B,N,2] (fully overwritten).  The
+ * gradient to the images is not provided: the reference samples dataset images and distance
+ * maps, which carry no gradient (main.py:241-265).                                              */
+int sv3d_texture_sample_backward(const float *images, const float *flow, const float *grad_out,
+                                 int32_t B, int32_t C, int32_t H, int32_t W, int32_t N,
+                                 float *grad_flow, void *stream);
+
+/* `compute_dt_barrier(mask, k)` (barrier != 0) and `compute_dt(mask)` (barrier == 0),
+ * utils/image.py:94-113, for a batch of masks [B,H,W] on the device (scipy's exact Euclidean
+ * distance transform on the host per sample there, main.py:259-260):
+ *   dist_out = EDT(1 - mask), dist_in = EDT(mask)      (distance of a non-zero pixel to the
+ *                                                        nearest zero pixel, 0 at zero pixels)
+ *   barrier: 1 / (1 + exp(-k (dist_out - dist_in) / max(H,W)));   plain: dist_out / max(H,W).
+ * A field without any zero pixel gets scipy's values for that case (distances to row -1,
+ * column 0).  H, W <= 4096.  `workspace` holds the per-row distances between the two launches:
+ * sv3d_distance_transform_workspace() bytes (4 per pixel), caller-owned like every buffer.      */
+int sv3d_distance_transform_workspace(int32_t B, int32_t H, int32_t W, size_t *bytes);
+int sv3d_distance_transform(const float *masks, int32_t B, int32_t H, int32_t W, int32_t barrier,
+                            float k, float *out, void *workspace, size_t workspace_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,8 +1,8 @@
 """Projection and quaternion helpers with the names and argument meaning of the
 reference's nnutils/geom_utils.py (reference lines cited per function).
 
-Plain torch (runs on any device, differentiable); this is the small O(B*V) input stage of
-the renderer call, not a kernel.
+The projection helpers are plain torch (any device, differentiable): the small O(B*V) input
+stage of the staged renderer call.  The texture samplers use the HIP sampler on GPU tensors.
 """
 import torch
 
@@ -56,20 +56,27 @@ def orthographic_proj_withz(X, cam, offset_z=0.):
     return proj + shift[:, None, :]
 
 
-def sample_textures(texture_flow, images):
-    """texture_flow [B,F,T,T,2] in [-1,1], images [B,3,N,N] -> [B,F,T*T,3]; geom_utils.py:11-26."""
+def _sample(texture_flow, images):
+    """[B,F,T*T,C] samples of `images` at `texture_flow`: bilinear, align_corners=True, zero
+    padding.  GPU tensors go through the HIP sampler, which writes the channels-last texel layout
+    directly; CPU tensors, more than 4 channels or images that need a gradient take torch's
+    grid_sample + permute as the reference does."""
     T = texture_flow.size(-2)
     F = texture_flow.size(1)
     grid = texture_flow.reshape(-1, F, T * T, 2)
-    samples = torch.nn.functional.grid_sample(images, grid, align_corners=True)
-    return samples.permute(0, 2, 3, 1)
+    if images.is_cuda and images.shape[1] <= 4 and not images.requires_grad:
+        import sv3d.texture
+        return sv3d.texture.texture_sample(images, grid.reshape(-1, F * T * T, 2)).view(-1, F, T * T, images.shape[1])
+    return torch.nn.functional.grid_sample(images, grid, align_corners=True).permute(0, 2, 3, 1)
+
+
+def sample_textures(texture_flow, images):
+    """texture_flow [B,F,T,T,2] in [-1,1], images [B,3,N,N] -> [B,F,T*T,3]; geom_utils.py:11-26."""
+    return _sample(texture_flow, images)
 
 
 def sample_textures_2(texture_flow, images):
     """As sample_textures but shaped [B,F,T,T,C]; geom_utils.py:29-46."""
     T = texture_flow.size(-2)
     F = texture_flow.size(1)
-    C = images.shape[1]
-    grid = texture_flow.reshape(-1, F, T * T, 2)
-    samples = torch.nn.functional.grid_sample(images, grid, align_corners=True)
-    return samples.reshape(-1, C, F, T, T).permute(0, 2, 3, 4, 1)
+    return _sample(texture_flow, images).reshape(-1, F, T, T, images.shape[1])

@@ -1,5 +1,6 @@
 """Losses of the reference's nnutils/loss_utils.py that reach native code: `chamfer_loss`
-(loss_utils.py:75-88) and the cotangent `LaplacianLoss` (loss_utils.py:565-583); the
+(loss_utils.py:75-88), the cotangent `LaplacianLoss` (loss_utils.py:565-583) and the
+texture-flow distance-transform loss (loss_utils.py:242-301); the
 reference's other losses are plain torch elementwise / matmul code that runs unchanged on
 PyTorch-ROCm.  Importing this module has no device side effects (the reference's module
 moves a constant to the GPU at import time, loss_utils.py:14-15).
@@ -39,3 +40,25 @@ class LaplacianLoss(object):
         self.Lx = self.laplacian(verts)
         Lx = self.Lx.view(-1, self.Lx.size(2))
         return torch.norm(Lx, p=2, dim=1).mean()
+
+
+def texture_dt_loss_per_instance(texture_flow, dist_transf, vis_rend=None, cams=None, verts=None, tex_pred=None):
+    """loss_utils.py:242-283: mean over a sample's texels of the distance map at the texel's flow.
+
+    texture_flow: B x F x T x T x 2 in [-1, 1]; dist_transf: B x 1 x N x N -> B.
+    The reference's interactive matplotlib branch (`vis_rend`) is not provided.
+    """
+    if vis_rend is not None:
+        raise NotImplementedError("the interactive visualisation branch is not provided")
+    from nnutils import geom_utils
+    return geom_utils.sample_textures(texture_flow, dist_transf).mean([1, 2, 3])
+
+
+def texture_dt_loss(texture_flow, dist_transf, vis_rend=None, cams=None, verts=None, tex_pred=None, probs=None,
+                    num_cams=1):
+    """loss_utils.py:286-301: the per-instance loss weighted by the camera probabilities
+    `probs` (Nc x B; uniform 1/Nc when omitted), summed over cameras, averaged over the batch."""
+    loss = texture_dt_loss_per_instance(texture_flow, dist_transf, vis_rend, cams, verts, tex_pred).view(num_cams, -1)
+    if probs is None:
+        probs = torch.ones_like(loss) / num_cams
+    return (loss * probs).sum(0).mean()
