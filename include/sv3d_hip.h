@@ -52,7 +52,10 @@ typedef struct sv3d_raster_params {
     int32_t texture_mode;  /* SV3D_TEX_*                                                      */
     int32_t texture_res;   /* R: surface textures hold R*R texels per face                    */
     int32_t double_side;   /* SoftRas fill_back: back faces take part in the colour softmax   */
-    int32_t reserved;
+    int32_t texture_batch; /* TB: texture sets in `textures`; 0 or B = one per image.  Otherwise  */
+                           /*     TB divides B and image b reads set b % TB -- the sets of       */
+                           /*     `torch.cat([textures] * num_cams)` (main.py:415) without the   */
+                           /*     copies.  grad_textures stays per image, [B, ...].              */
     float background[3];
     float near_plane;      /* 1   */
     float far_plane;       /* 100 */

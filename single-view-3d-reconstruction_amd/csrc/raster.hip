@@ -63,6 +63,7 @@ __host__ __device__ constexpr bool mode_vertex(int mode) { return mode == SV3D_T
 
 struct DevParams {
     int B, F, S, aa, mode, R, double_side;
+    int TB;                       // texture sets: image b reads set b % TB (TB == B: one per image)
     float bg0, bg1, bg2;
     float near_plane, far_plane, eps;
     float neg_l2e_over_sigma;     // -log2(e) / sigma
@@ -485,6 +486,7 @@ __global__ __launch_bounds__(kThreads * SPLIT) void raster_forward_kernel(
 #endif
     const int tiles_x = (P.S + kTile - 1) / kTile;
     const int b = blockIdx.x % P.B;
+    const int tb = P.TB == P.B ? b : b % P.TB;          // texture set of this image
     const int tile = blockIdx.x / P.B;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -592,11 +594,11 @@ __global__ __launch_bounds__(kThreads * SPLIT) void raster_forward_kernel(
                         const int fid = s_ids[jj];
                         if (MODE == SV3D_TEX_SURFACE) {
                             const int Ts = P.R * P.R;
-                            const float *tp = tex + (((size_t)b * F + fid) * Ts +
+                            const float *tp = tex + (((size_t)tb * F + fid) * Ts +
                                                      texel_index(d.n0, d.n1, d.n2, P.R)) * 3;
                             kc[0] = tp[0]; kc[1] = tp[1]; kc[2] = tp[2];
                         } else {
-                            const float *tp = tex + ((size_t)b * F + fid) * (3 * NC);
+                            const float *tp = tex + ((size_t)tb * F + fid) * (3 * NC);
 #pragma unroll
                             for (int c = 0; c < NC; ++c)
                                 kc[c] = d.n0 * tp[c] + d.n1 * tp[NC + c] + d.n2 * tp[2 * NC + c];
@@ -843,6 +845,7 @@ __global__ __launch_bounds__(kThreads) void raster_backward_kernel(
     const int gf = wg * 4 + wave;               // global face index b*F + f
     if (gf >= P.B * P.F) return;                // whole wave; no block-level barrier is used
     const int b = gf / P.F;
+    const int tgf = P.TB == P.B ? gf : gf - (b - b % P.TB) * P.F;     // the face in its texture set
     const int S = P.S;
     const FaceRec r = load_rec(rec + (size_t)gf * kRec4);
     int col0, col1, row0, row1;
@@ -867,13 +870,13 @@ __global__ __launch_bounds__(kThreads) void raster_backward_kernel(
         for (int i = lane; i < ncopy * Ts * 3; i += 64) s_tex[i] = 0.f;
         if (staged) {
             for (int i = lane; i < Ts; i += 64) {
-                const float *tp = tex + ((size_t)gf * Ts + i) * 3;
+                const float *tp = tex + ((size_t)tgf * Ts + i) * 3;
                 reinterpret_cast<float4 *>(s_val)[i] = make_float4(tp[0], tp[1], tp[2], 0.f);
             }
         }
     } else if (mode_vertex(MODE)) {
 #pragma unroll
-        for (int i = 0; i < 3 * NC; ++i) tv[i] = tex[(size_t)gf * (3 * NC) + i];
+        for (int i = 0; i < 3 * NC; ++i) tv[i] = tex[(size_t)tgf * (3 * NC) + i];
     }
 
     float acc[9];
@@ -998,7 +1001,7 @@ __global__ __launch_bounds__(kThreads) void raster_backward_kernel(
                         const float4 tv4 = reinterpret_cast<const float4 *>(s_val)[tid];
                         kc[0] = tv4.x; kc[1] = tv4.y; kc[2] = tv4.z;
                     } else {
-                        const float *tp = tex + ((size_t)gf * Ts + tid) * 3;
+                        const float *tp = tex + ((size_t)tgf * Ts + tid) * 3;
                         kc[0] = tp[0]; kc[1] = tp[1]; kc[2] = tp[2];
                     }
                 } else {
@@ -1114,11 +1117,14 @@ int make_dev_params(const sv3d_raster_params *p, DevParams &d)
     if (!(p->sigma > 0.f) || !(p->gamma > 0.f) || !(p->dist_eps > 0.f) || !(p->dist_eps < 1.f))
         return SV3D_ERR_INVALID_ARG;
     if (!(p->far_plane > p->near_plane)) return SV3D_ERR_INVALID_ARG;
+    if (p->texture_batch < 0 || (p->texture_batch > 0 && p->batch % p->texture_batch != 0))
+        return SV3D_ERR_INVALID_ARG;
     if (p->raster_size > 4096 || p->batch > 65535) return SV3D_ERR_UNSUPPORTED;
     if ((long)p->batch * p->num_faces > 0x7fffffffL / 4) return SV3D_ERR_UNSUPPORTED;
     if (p->texture_mode == SV3D_TEX_SURFACE && p->texture_res > 36) return SV3D_ERR_UNSUPPORTED;
     const double l2e = 1.4426950408889634;
     d.B = p->batch; d.F = p->num_faces; d.S = p->raster_size; d.aa = p->aa;
+    d.TB = p->texture_batch > 0 ? p->texture_batch : p->batch;
     d.mode = p->texture_mode; d.R = p->texture_mode == SV3D_TEX_SURFACE ? p->texture_res : 1;
     d.double_side = p->double_side;
     d.bg0 = p->background[0]; d.bg1 = p->background[1]; d.bg2 = p->background[2];

@@ -19,7 +19,11 @@ def convert_as(src, trg):
 
 class SoftNeuralRenderer(torch.nn.Module):
     """forward(vertices [B,V,3], faces [B,F,3], cams [B,7], textures=None) ->
-    masks [B,H,W] when textures is None, else RGB [B,3,H,W]."""
+    masks [B,H,W] when textures is None, else RGB [B,3,H,W].
+
+    `textures` may hold fewer sets than there are images: TB sets with B a multiple of TB, image b
+    using set b % TB -- what `torch.cat([textures] * num_cams)` (main.py:415) builds, without the
+    copies (fused camera stage only)."""
 
     def __init__(self, img_size=256, texture_type='surface'):
         super(SoftNeuralRenderer, self).__init__()
@@ -92,7 +96,14 @@ class SoftNeuralRenderer(torch.nn.Module):
         if lighting.is_identity():
             return sv3d.render(vertices, cams, faces, textures, r.image_size, **kw)
         fv = sv3d.project_gather(vertices, cams, faces, self.offset_z, scale, shift)
-        lit = textures * lighting.surface_light(fv)[:, :, None, :]
+        light = lighting.surface_light(fv)[:, :, None, :]
+        if textures.shape[0] != fv.shape[0]:       # one texture set for several cameras
+            sets = textures.shape[0]
+            if sets < 1 or fv.shape[0] % sets != 0:
+                raise ValueError("%d texture sets do not divide %d images" % (sets, fv.shape[0]))
+            lit = (textures[None] * light.view((-1, sets) + tuple(light.shape[1:]))).flatten(0, 1)
+        else:
+            lit = textures * light
         kw.pop('offset_z'), kw.pop('scale'), kw.pop('shift')
         return sv3d.soft_rasterize(fv, lit, r.image_size, **kw)
 

@@ -31,7 +31,7 @@ class RasterParams(ctypes.Structure):
         ("batch", ctypes.c_int32), ("num_faces", ctypes.c_int32),
         ("raster_size", ctypes.c_int32), ("aa", ctypes.c_int32),
         ("texture_mode", ctypes.c_int32), ("texture_res", ctypes.c_int32),
-        ("double_side", ctypes.c_int32), ("reserved", ctypes.c_int32),
+        ("double_side", ctypes.c_int32), ("texture_batch", ctypes.c_int32),
         ("background", ctypes.c_float * 3),
         ("near_plane", ctypes.c_float), ("far_plane", ctypes.c_float), ("eps", ctypes.c_float),
         ("sigma", ctypes.c_float), ("dist_eps", ctypes.c_float), ("gamma", ctypes.c_float),
@@ -110,7 +110,7 @@ def make_params(batch, num_faces, raster_size, aa, texture_mode, texture_res, do
     p = RasterParams()
     p.batch, p.num_faces, p.raster_size, p.aa = int(batch), int(num_faces), int(raster_size), int(aa)
     p.texture_mode, p.texture_res = int(texture_mode), int(texture_res)
-    p.double_side, p.reserved = int(bool(double_side)), 0
+    p.double_side, p.texture_batch = int(bool(double_side)), 0
     p.background[0], p.background[1], p.background[2] = (float(c) for c in background)
     p.near_plane, p.far_plane, p.eps = float(near), float(far), float(eps)
     p.sigma, p.dist_eps, p.gamma = float(sigma), float(dist_eps), float(gamma)

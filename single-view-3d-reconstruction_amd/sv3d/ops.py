@@ -62,9 +62,35 @@ def _check_raster_inputs(fv, tex, texture_mode, texture_res):
         return
     if tex is None:
         raise ValueError("textures required for texture_mode %d" % texture_mode)
-    want = _texture_shape(fv.shape[0], fv.shape[1], texture_mode, texture_res)
-    if tuple(tex.shape) != want:
-        raise ValueError("textures must be %s, got %s" % (want, tuple(tex.shape)))
+    _check_textures(tex, fv.shape[0], fv.shape[1], texture_mode, texture_res)
+
+
+def _check_textures(tex, B, F, texture_mode, texture_res):
+    """Textures are per image, or one set per group of images: a batch TB that divides B, image b
+    reading set b % TB (the order of `torch.cat([textures] * num_cams)`, main.py:415)."""
+    want = _texture_shape(B, F, texture_mode, texture_res)
+    if tex is None or tex.dim() != 4 or tuple(tex.shape[1:]) != want[1:] or tex.shape[0] < 1 \
+            or B % tex.shape[0] != 0:
+        raise ValueError("textures must be %s (or a leading size that divides %d), got %s"
+                         % (want, B, None if tex is None else tuple(tex.shape)))
+
+
+def _with_texture_batch(p, tex):
+    """Sets the struct's texture batch for this call (0 = one set per image)."""
+    p.texture_batch = 0 if tex is None or tex.shape[0] == p.batch else tex.shape[0]
+    return p
+
+
+def _grad_textures_buffer(tex, B):
+    """Per-image texture gradients [B, ...] for the kernel to fill."""
+    return torch.empty((B,) + tuple(tex.shape[1:]), dtype=torch.float32, device=tex.device)
+
+
+def _fold_grad_textures(gtex, tex):
+    """Sums the per-image gradients over the images that shared a texture set."""
+    if gtex.shape[0] == tex.shape[0]:
+        return gtex
+    return gtex.view((gtex.shape[0] // tex.shape[0],) + tuple(tex.shape)).sum(0)
 
 
 # ---- soft rasterizer -----------------------------------------------------------------
@@ -76,8 +102,8 @@ def soft_rasterize_op(face_vertices: Tensor, textures: Optional[Tensor], raster_
     _check_raster_inputs(face_vertices, textures, texture_mode, texture_res)
     fv = _f32c(face_vertices)
     tex = _f32c(textures) if texture_mode != L.SV3D_TEX_NONE else None
-    p = _params(fv, raster_size, aa, texture_mode, texture_res, double_side, background,
-                near, far, eps, sigma, dist_eps, gamma)
+    p = _with_texture_batch(_params(fv, raster_size, aa, texture_mode, texture_res, double_side, background,
+                                    near, far, eps, sigma, dist_eps, gamma), tex)
     rec_b, saved_b, _ = L.raster_sizes(p)
     H = raster_size // aa
     with torch.cuda.device(fv.device):
@@ -112,18 +138,20 @@ def soft_rasterize_backward_op(grad_rgba: Tensor, textures: Optional[Tensor], fa
                                need_textures: bool) -> Tuple[Tensor, Tensor]:
     g = _f32c(grad_rgba)
     tex = _f32c(textures) if texture_mode != L.SV3D_TEX_NONE else None
-    p = L.make_params(batch, num_faces, raster_size, aa, texture_mode, texture_res, double_side,
-                      background, near, far, eps, sigma, dist_eps, gamma)
+    p = _with_texture_batch(L.make_params(batch, num_faces, raster_size, aa, texture_mode, texture_res,
+                                          double_side, background, near, far, eps, sigma, dist_eps, gamma), tex)
     _, _, ws_b = L.raster_sizes(p)
     with torch.cuda.device(g.device):
         gfv = torch.empty((batch, num_faces, 3, 3), dtype=torch.float32, device=g.device)
-        gtex = torch.empty_like(tex) if (tex is not None and need_textures) else \
+        gtex = _grad_textures_buffer(tex, batch) if (tex is not None and need_textures) else \
             torch.empty(0, dtype=torch.float32, device=g.device)
         ws = torch.empty(ws_b // 4, dtype=torch.float32, device=g.device)
         L.check(L.lib().sv3d_raster_backward(ctypes.byref(p), _ptr(tex), _ptr(face_rec),
                                              _ptr(pixel_saved), _ptr(g), _ptr(gfv), _ptr(gtex),
                                              _ptr(ws), ctypes.c_size_t(ws_b), _stream(g)),
                 "sv3d_raster_backward")
+        if tex is not None and need_textures:
+            gtex = _fold_grad_textures(gtex, tex)
     return gfv, gtex
 
 
@@ -440,12 +468,10 @@ def render_op(vertices: Tensor, cams: Tensor, faces: Tensor, textures: Optional[
     v, c, f = _f32c(vertices), _f32c(cams), faces.contiguous()
     B, F = v.shape[0], f.shape[1]
     if texture_mode != L.SV3D_TEX_NONE:
-        want = _texture_shape(B, F, texture_mode, texture_res)
-        if textures is None or tuple(textures.shape) != want:
-            raise ValueError("textures must be %s" % (want,))
+        _check_textures(textures, B, F, texture_mode, texture_res)
     tex = _f32c(textures) if texture_mode != L.SV3D_TEX_NONE else None
-    p = L.make_params(B, F, raster_size, aa, texture_mode, texture_res, double_side, background,
-                      near, far, eps, sigma, dist_eps, gamma)
+    p = _with_texture_batch(L.make_params(B, F, raster_size, aa, texture_mode, texture_res, double_side,
+                                          background, near, far, eps, sigma, dist_eps, gamma), tex)
     rec_b, saved_b, _ = L.raster_sizes(p)
     H = raster_size // aa
     with torch.cuda.device(v.device):
@@ -482,12 +508,12 @@ def render_backward_op(grad_rgba: Tensor, vertices: Tensor, cams: Tensor, faces:
     g, v, c = _f32c(grad_rgba), _f32c(vertices), _f32c(cams)
     tex = _f32c(textures) if texture_mode != L.SV3D_TEX_NONE else None
     B, F = v.shape[0], faces.shape[1]
-    p = L.make_params(B, F, raster_size, aa, texture_mode, texture_res, double_side, background,
-                      near, far, eps, sigma, dist_eps, gamma)
+    p = _with_texture_batch(L.make_params(B, F, raster_size, aa, texture_mode, texture_res, double_side,
+                                          background, near, far, eps, sigma, dist_eps, gamma), tex)
     _, _, ws_b = L.raster_sizes(p)
     with torch.cuda.device(g.device):
         gfv = torch.empty((B, F, 3, 3), dtype=torch.float32, device=g.device)
-        gtex = torch.empty_like(tex) if (tex is not None and need_textures) else \
+        gtex = _grad_textures_buffer(tex, B) if (tex is not None and need_textures) else \
             torch.empty(0, dtype=torch.float32, device=g.device)
         ws = torch.empty(ws_b // 4, dtype=torch.float32, device=g.device)
         gv, gc = torch.empty_like(v), torch.empty_like(c)
@@ -498,6 +524,8 @@ def render_backward_op(grad_rgba: Tensor, vertices: Tensor, cams: Tensor, faces:
         m = L.make_mesh_input(v, c, faces, offset_z, scale, (0.0, 0.0, 0.0))
         L.check(L.lib().sv3d_project_scatter(ctypes.byref(m), B, F, _ptr(gfv), _ptr(gv), _ptr(gc), st),
                 "sv3d_project_scatter")
+        if tex is not None and need_textures:
+            gtex = _fold_grad_textures(gtex, tex)
     return gv, gc, gtex
 
 
@@ -562,9 +590,7 @@ def render(vertices, cams, faces, textures=None, image_size=256, *, offset_z=0.0
         _check_mesh(vertices, cams, f32)
         B, F = vertices.shape[0], f32.shape[1]
         if mode != L.SV3D_TEX_NONE:
-            want = _texture_shape(B, F, mode, res)
-            if tuple(textures.shape) != want:
-                raise ValueError("textures must be %s" % (want,))
+            _check_textures(textures, B, F, mode, res)
         key = (B, F, int(image_size) * aa, aa, mode, res, bool(fill_back),
                tuple(float(c) for c in background_color), float(near), float(far), float(eps),
                float(sigma_val), float(dist_eps), float(gamma_val))
@@ -612,11 +638,11 @@ def _cached_params(key):
 
 def _raster_backward_call(p, g, tex, rec, saved, need_tex, B, F):
     gfv = torch.empty((B, F, 3, 3), dtype=torch.float32, device=g.device)
-    gtex = torch.empty_like(tex) if (tex is not None and need_tex) else None
-    L.check(L.lib().sv3d_raster_backward(ctypes.byref(p), _ptr(tex), _ptr(rec), _ptr(saved), _ptr(g),
-                                         _ptr(gfv), _ptr(gtex), None, ctypes.c_size_t(0), _stream(g)),
-            "sv3d_raster_backward")
-    return gfv, gtex
+    gtex = _grad_textures_buffer(tex, B) if (tex is not None and need_tex) else None
+    L.check(L.lib().sv3d_raster_backward(ctypes.byref(_with_texture_batch(p, tex)), _ptr(tex), _ptr(rec),
+                                         _ptr(saved), _ptr(g), _ptr(gfv), _ptr(gtex), None, ctypes.c_size_t(0),
+                                         _stream(g)), "sv3d_raster_backward")
+    return gfv, (_fold_grad_textures(gtex, tex) if gtex is not None else None)
 
 
 class _RenderFn(torch.autograd.Function):
@@ -629,6 +655,7 @@ class _RenderFn(torch.autograd.Function):
         x = _f32c(geom)
         tex = _f32c(textures) if key[4] != L.SV3D_TEX_NONE else None
         p, rec_b, saved_b = _cached_params(key)
+        _with_texture_batch(p, tex)
         B, S, aa = key[0], key[2], key[3]
         dev = x.device
         with torch.cuda.device(dev):

@@ -226,3 +226,34 @@ def test_shared_pass_renders_equal_the_separate_calls():
         assert rel_err(x, y) < 1e-5                 # same gradients, summed in a different order
     with pytest.raises(ValueError):
         tex_r.render_parts(v, f, cams, parts)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ambient", [True, False])
+def test_texture_sets_shared_by_camera_hypotheses(ambient):
+    """main.py:413-418 renders `num_cams` camera hypotheses of the same meshes with
+    `torch.cat([textures] * num_cams)`; passing the TB texture sets once must give the same image
+    and the gradient summed over the hypotheses."""
+    from nnutils.softras import SoftNeuralRenderer
+    verts, faces = load_mesh(3)
+    TB, Nc, T = 2, 3, 4
+    B = TB * Nc
+    g = torch.Generator().manual_seed(5)
+    v = random_vertices(verts, TB, seed=2).repeat(Nc, 1, 1).cuda()
+    cams = random_cams(B, seed=4).cuda()
+    f = faces[None].expand(B, -1, -1).cuda()
+    tex = torch.rand(TB, faces.shape[0], T * T, 3, generator=g)
+    w = torch.rand(B, 3, 64, 64, generator=g).cuda()
+    r = SoftNeuralRenderer(img_size=64)
+    if ambient:
+        r.ambient_light_only()
+    t_cat = tex.cuda().requires_grad_(True)
+    img_cat = r.forward(v, f, cams, torch.cat([t_cat] * Nc))
+    (img_cat * w).sum().backward()
+    t_set = tex.cuda().requires_grad_(True)
+    img_set = r.forward(v, f, cams, t_set)
+    (img_set * w).sum().backward()
+    assert torch.equal(img_set, img_cat)
+    assert rel_err(t_set.grad, t_cat.grad) < 1e-6          # same terms, summed in another order
+    with pytest.raises(ValueError):
+        r.forward(v, f, cams, tex[:1].repeat(4, 1, 1, 1).cuda())     # 4 does not divide 6
