@@ -134,6 +134,8 @@ class ShapeTrainer(train_utils.Trainer):
         verts, faces = meshgen.icosphere(o.subdivide)
         verts, faces = torch.from_numpy(verts), torch.from_numpy(faces)
         self.model = MeshNetLite(verts, faces.long(), o.num_hypo_cams, o.tex_size)
+        if o.channels_last:
+            self.model = self.model.to(memory_format=torch.channels_last)
         self.part_basis_generator = nn.Linear(o.num_parts, verts.shape[0], bias=False)   # vertex part logits
         self.renderer = SoftNeuralRenderer(o.img_size)
         self.tex_renderer = SoftNeuralRenderer(o.img_size)
@@ -157,7 +159,8 @@ class ShapeTrainer(train_utils.Trainer):
         masks_gt = torch.cat([self.masks, self.masks.flip(-1)])
         B2 = all_imgs.shape[0]
         model = train_utils.unwrap(self.model)
-        pred_v, cams, cam_logits, flow = self.model(all_imgs)
+        enc_in = all_imgs.contiguous(memory_format=torch.channels_last) if o.channels_last else all_imgs
+        pred_v, cams, cam_logits, flow = self.model(enc_in)
         textures = geom_utils.sample_textures(flow, all_imgs)               # main.py:395
         faces = model.faces[None].expand(B2, -1, -1)
         vs = torch.cat([pred_v] * Nc)                                       # main.py:413-415
@@ -219,6 +222,7 @@ def parse(argv=None):
     p.add_argument('--num_parts', type=int, default=8)
     p.add_argument('--chamf_loss_wt', type=float, default=1.0)
     p.add_argument('--dataset_size', type=int, default=512)
+    p.add_argument('--channels_last', type=int, default=0, help='encoder weights and activations in NHWC')
     p.add_argument('--warmup_iter', type=int, default=0, help='untimed steps before the timed ones')
     p.add_argument('--dt_loss_wt', type=float, default=0.01, help='weight of the texture-flow distance-map loss')
     p.add_argument('--host_dt', type=int, default=0,
