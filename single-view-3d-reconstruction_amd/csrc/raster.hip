@@ -184,7 +184,7 @@ __device__ inline PairGeom pair_geom(const FaceRec &r, const Pixel &px, const De
     g.t = g.k0 ? t0 : (g.k1 ? t1 : t2);
     g.dx = g.k0 ? d0x : (g.k1 ? d1x : d2x);
     g.dy = g.k0 ? d0y : (g.k1 ? d1y : d2y);
-    g.inside = (g.w0 > 0.f) && (g.w1 > 0.f) && (g.w2 > 0.f);
+    g.inside = (g.w0 > 0.f) & (g.w1 > 0.f) & (g.w2 > 0.f);       // no short circuit: plain mask ands
     // A pixel outside the face's cull box (bbox widened by sqrt(threshold)) is farther than
     // sqrt(threshold) from the triangle, so the distance test alone implements both culls.
     g.act = g.inside || g.d2 < P.threshold;
@@ -218,7 +218,7 @@ __device__ inline float pair_one_minus_D(const FaceRec &r, const Pixel &px, cons
     const float c0 = r.e0y * a0x - r.e0x * a0y;
     const float c1 = r.e1y * a1x - r.e1x * a1y;
     const float c2 = r.e2y * a2x - r.e2x * a2y;
-    const bool inside = (c1 * r.inv_det > 0.f) && (c2 * r.inv_det > 0.f) && (c0 * r.inv_det > 0.f);
+    const bool inside = (c1 * r.inv_det > 0.f) & (c2 * r.inv_det > 0.f) & (c0 * r.inv_det > 0.f);
     const float e = ex2((inside ? d2 : -d2) * -P.neg_l2e_over_sigma);
     return rcp(1.f + e);
 }
@@ -825,7 +825,10 @@ __device__ inline float wave_sum_lane63(float v)
 // `saved` are the forward's per-raster-pixel aggregates (1 float in silhouette mode, 6 in the
 // colour modes) and `grad_rgba` the incoming gradient at output resolution; both are folded per
 // visit, so there is no per-pixel preparation pass and no scratch buffer.
-template <int MODE, bool LO>
+// HALVES = 2 (small launches): two waves per face, each taking every other 64-pixel step and
+// the first of them adding the second's totals, exchanged through LDS, before it writes.  With
+// few faces the launch is bound by its longest waves, not by issue slots, and this halves them.
+template <int MODE, bool LO, int HALVES>
 __global__ __launch_bounds__(kThreads) void raster_backward_kernel(
     DevParams P, const float4 *__restrict__ rec, const uint2 *__restrict__ pbox,
     const float *__restrict__ tex, const float *__restrict__ saved, const float *__restrict__ grad_rgba,
@@ -842,8 +845,12 @@ __global__ __launch_bounds__(kThreads) void raster_backward_kernel(
     // work would unbalance the XCDs (measured: +1 us at batch 8, -2..5 % from batch 64 on).
     const int nwg = gridDim.x, xcd = blockIdx.x & 7, per = nwg >> 3, rem = nwg & 7;
     const int wg = P.B >= 32 ? xcd * per + min(xcd, rem) + (blockIdx.x >> 3) : blockIdx.x;
-    const int gf = wg * 4 + wave;               // global face index b*F + f
-    if (gf >= P.B * P.F) return;                // whole wave; no block-level barrier is used
+    // global face index b*F + f, and which share of its steps this wave takes
+    const int half = HALVES == 2 ? (wave & 1) : 0;
+    const int gf_raw = HALVES == 2 ? wg * 2 + (wave >> 1) : wg * 4 + wave;
+    const bool live = gf_raw < P.B * P.F;
+    if (HALVES == 1 && !live) return;           // whole wave; HALVES == 1 uses no block-level barrier
+    const int gf = live ? gf_raw : P.B * P.F - 1;       // HALVES == 2: idle waves still reach the barrier
     const int b = gf / P.F;
     const int tgf = P.TB == P.B ? gf : gf - (b - b % P.TB) * P.F;     // the face in its texture set
     const int S = P.S;
@@ -851,7 +858,7 @@ __global__ __launch_bounds__(kThreads) void raster_backward_kernel(
     int col0, col1, row0, row1;
     unpack_box(pbox[gf], col0, col1, row0, row1);
     const int bw = col1 - col0 + 1, bh = row1 - row0 + 1;
-    const int npix = (bw > 0 && bh > 0) ? bw * bh : 0;
+    const int npix = (live && bw > 0 && bh > 0) ? bw * bh : 0;
     const float inv_bw = bw > 0 ? rcp((float)bw) : 0.f;     // the two fix-ups below absorb its last-bit error
 
     // SURFACE: the face's texel gradients accumulate in wave-private LDS tables.  Lanes of one
@@ -887,7 +894,7 @@ __global__ __launch_bounds__(kThreads) void raster_backward_kernel(
     for (int i = 0; i < 3 * NC; ++i) tacc[i] = 0.f;
 
     // Lanes enumerate the box row-major, 64 pixels per step.  (rx, ry) = position inside the box,
-    // kept as exact small integers in fp32 and advanced by 64 pixels per step with at most one
+    // kept as exact small integers in fp32 and advanced by kStride pixels per step with at most one
     // row wrap per lane; the per-pixel inputs of step i+1 are requested before step i is
     // evaluated so that their latency overlaps the arithmetic.
     const float bw_f = (float)bw, bh_f = (float)bh;
@@ -897,9 +904,11 @@ __global__ __launch_bounds__(kThreads) void raster_backward_kernel(
     const float *saved_b = saved + (size_t)b * S * S * PP;
     const int H = S / P.aa;
     const float gscale = P.aa == 2 ? 0.25f : 1.f;
-    const float adv_y = bw > 0 ? (float)(64 / bw) : 0.f, adv_x = bw > 0 ? (float)(64 % bw) : 0.f;
-    float ry_f = floorf(((float)lane + 0.5f) * inv_bw);
-    float rx_f = fmaf(-ry_f, bw_f, (float)lane);
+    constexpr int kStride = 64 * HALVES;        // pixels between two steps of one wave
+    const float adv_y = bw > 0 ? (float)(kStride / bw) : 0.f, adv_x = bw > 0 ? (float)(kStride % bw) : 0.f;
+    const float lane0 = (float)(half * 64 + lane);
+    float ry_f = floorf((lane0 + 0.5f) * inv_bw);
+    float rx_f = fmaf(-ry_f, bw_f, lane0);
     if (rx_f < 0.f) { ry_f -= 1.f; rx_f += bw_f; }
     if (rx_f >= bw_f) { ry_f += 1.f; rx_f -= bw_f; }
 
@@ -962,10 +971,10 @@ __global__ __launch_bounds__(kThreads) void raster_backward_kernel(
     };
 
     PixIn nxt;
-    if (npix > 0) nxt = fetch();
-    for (int base = 0; base < npix; base += 64) {
+    if (npix > half * 64) nxt = fetch();
+    for (int base = half * 64; base < npix; base += kStride) {
         const PixIn in = nxt;
-        if (base + 64 < npix) nxt = fetch();        // wave-uniform
+        if (base + kStride < npix) nxt = fetch();   // wave-uniform
         const float xp = in.xp, yp = in.yp;
         const bool valid = in.valid;
         // fold the gradient with the aggregates: g_alpha A and g_k / ssum
@@ -1081,6 +1090,34 @@ __global__ __launch_bounds__(kThreads) void raster_backward_kernel(
 #pragma unroll
     for (int i = 0; i < 9; ++i)                     // silhouettes carry no depth gradient
         tot[i] = (MODE == SV3D_TEX_NONE && i % 3 == 2) ? 0.f : wave_sum_lane63(acc[i]);
+    float ttot[3 * NC];
+    if (mode_vertex(MODE) && gtex != nullptr) {
+#pragma unroll
+        for (int i = 0; i < 3 * NC; ++i) ttot[i] = wave_sum_lane63(tacc[i]);
+    }
+    if (HALVES == 2) {
+        // the odd wave of a face hands its totals to the even one (its texel tables stay where
+        // they are, in its own LDS region, and are read from there below)
+        __shared__ float s_half[2][9 + 3 * NC];
+        if (half == 1 && lane == 63) {
+#pragma unroll
+            for (int i = 0; i < 9; ++i) s_half[wave >> 1][i] = tot[i];
+            if (mode_vertex(MODE) && gtex != nullptr) {
+#pragma unroll
+                for (int i = 0; i < 3 * NC; ++i) s_half[wave >> 1][9 + i] = ttot[i];
+            }
+        }
+        __syncthreads();
+        if (half == 1 || !live) return;
+        if (lane == 63) {
+#pragma unroll
+            for (int i = 0; i < 9; ++i) tot[i] += s_half[wave >> 1][i];
+            if (mode_vertex(MODE) && gtex != nullptr) {
+#pragma unroll
+                for (int i = 0; i < 3 * NC; ++i) ttot[i] += s_half[wave >> 1][9 + i];
+            }
+        }
+    }
     if (lane == 63) {
         float *o = gfv + (size_t)gf * 9;
 #pragma unroll
@@ -1088,16 +1125,19 @@ __global__ __launch_bounds__(kThreads) void raster_backward_kernel(
     }
     if (gtex != nullptr) {
         if (MODE == SV3D_TEX_SURFACE) {
+            const float *s_other = s_tex + tex_lds_floats(Ts);      // HALVES == 2: the odd wave's tables
             for (int i = lane; i < Ts * 3; i += 64) {
                 float t = s_tex[i];
                 for (int c = 1; c < ncopy; ++c) t += s_tex[c * Ts * 3 + i];
+                if (HALVES == 2) {
+                    for (int c = 0; c < ncopy; ++c) t += s_other[c * Ts * 3 + i];
+                }
                 gtex[(size_t)gf * Ts * 3 + i] = t;
             }
         } else if (mode_vertex(MODE)) {
+            if (lane == 63) {
 #pragma unroll
-            for (int i = 0; i < 3 * NC; ++i) {
-                const float t = wave_sum_lane63(tacc[i]);
-                if (lane == 63) gtex[(size_t)gf * (3 * NC) + i] = t;
+                for (int i = 0; i < 3 * NC; ++i) gtex[(size_t)gf * (3 * NC) + i] = ttot[i];
             }
         }
     }
@@ -1106,6 +1146,8 @@ __global__ __launch_bounds__(kThreads) void raster_backward_kernel(
 // ------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------
+constexpr long kBackwardHalvesMaxFaces = 16384;
+
 int make_dev_params(const sv3d_raster_params *p, DevParams &d)
 {
     if (!p) return SV3D_ERR_INVALID_ARG;
@@ -1277,18 +1319,26 @@ int raster_backward_impl(const sv3d_raster_params *p, const float *textures, con
     const float4 *rec = static_cast<const float4 *>(face_rec);
     const uint2 *pbox = reinterpret_cast<const uint2 *>(static_cast<const float *>(face_rec) + rec_floats(d));
     const float *saved = static_cast<const float *>(pixel_saved);
-    const dim3 fgrid((d.B * d.F + 3) / 4), block(kThreads);
+    // two waves per face while the launch is small: below two residency rounds of whole-face waves
+    const bool halves = (long)d.B * d.F <= kBackwardHalvesMaxFaces;
+    const dim3 fgrid(halves ? (d.B * d.F + 1) / 2 : (d.B * d.F + 3) / 4), block(kThreads);
     if (ev_start) (void)hipEventRecord(ev_start, s);
     const bool lo = (d.S & (d.S - 1)) != 0;         // raster size not a power of two: see struct Pixel
     const size_t lds = d.mode == SV3D_TEX_SURFACE ? (size_t)4 * tex_lds_floats(d.R * d.R) * sizeof(float) : 0;
     float *gt = d.mode == SV3D_TEX_NONE ? nullptr : grad_textures;
 #define SV3D_LAUNCH_BWD(M)                                                                              \
     do {                                                                                                \
-        if (lo)                                                                                         \
-            hipLaunchKernelGGL((raster_backward_kernel<M, true>), fgrid, block, lds, s, d, rec, pbox,   \
+        if (lo && halves)                                                                               \
+            hipLaunchKernelGGL((raster_backward_kernel<M, true, 2>), fgrid, block, lds, s, d, rec, pbox,   \
+                               textures, saved, grad_rgba, grad_face_vertices, gt);                     \
+        else if (lo)                                                                                    \
+            hipLaunchKernelGGL((raster_backward_kernel<M, true, 1>), fgrid, block, lds, s, d, rec, pbox,   \
+                               textures, saved, grad_rgba, grad_face_vertices, gt);                     \
+        else if (halves)                                                                                \
+            hipLaunchKernelGGL((raster_backward_kernel<M, false, 2>), fgrid, block, lds, s, d, rec, pbox,  \
                                textures, saved, grad_rgba, grad_face_vertices, gt);                     \
         else                                                                                            \
-            hipLaunchKernelGGL((raster_backward_kernel<M, false>), fgrid, block, lds, s, d, rec, pbox,  \
+            hipLaunchKernelGGL((raster_backward_kernel<M, false, 1>), fgrid, block, lds, s, d, rec, pbox,  \
                                textures, saved, grad_rgba, grad_face_vertices, gt);                     \
     } while (0)
     if (d.mode == SV3D_TEX_NONE) SV3D_LAUNCH_BWD(SV3D_TEX_NONE);
