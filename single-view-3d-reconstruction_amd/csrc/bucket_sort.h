@@ -63,5 +63,27 @@ __device__ inline int next_slot(const int *bucket, int s0, int s1, int last)
     return m;
 }
 
+// Calls fn(slot) for the slots of bucket [s0, s1) -- those with key `key` -- in ascending slot
+// order.  Short buckets are walked by repeated minimum search (k^2 steps for k slots); a bucket so
+// long that k^2 exceeds the number of slots is walked by scanning the keys of all slots instead,
+// which bounds a thread's work by nslots whatever the keys are (a vertex shared by every face,
+// a cloud collapsed onto one point).
+template <typename Fn>
+__device__ inline void for_each_slot_ascending(const int *bucket, int s0, int s1, const int32_t *__restrict__ fb,
+                                               int key, int V, int nslots, Fn fn)
+{
+    const int k = s1 - s0;
+    if ((long)k * k <= (long)nslots) {
+        int last = -1;
+        for (int i = s0; i < s1; ++i) {
+            last = next_slot(bucket, s0, s1, last);
+            fn(last);
+        }
+    } else {
+        for (int i = 0; i < nslots; ++i)
+            if (min(max(fb[i], 0), V - 1) == key) fn(i);
+    }
+}
+
 }  // namespace sv3d_dev
 #endif

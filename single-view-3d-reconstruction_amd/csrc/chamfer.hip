@@ -266,19 +266,16 @@ __global__ __launch_bounds__(sv3d_dev::kSortThreads) void chamfer_grad_sorted_ke
             az = g * (oz - oth[3 * j + 2]);
         }
         if (gd_oth != nullptr) {
-            const int s0 = start[i], s1 = fill[i];
-            int last = -1;
-            for (int k = s0; k < s1; ++k) {
-                last = sv3d_dev::next_slot(bucket, s0, s1, last);
+            sv3d_dev::for_each_slot_ascending(bucket, start[i], fill[i], idx_oth, i, n_own, n_oth, [&](int j) {
                 // an index outside the own cloud was clamped into a bucket by the sort; the scan
                 // form never matches it, so it is skipped here as well
-                if (idx_oth[last] != i) continue;
-                const float g = 2.f * gd_oth[(size_t)b * n_oth + last];
-                const float *o = oth + 3 * (size_t)last;
+                if (idx_oth[j] != i) return;
+                const float g = 2.f * gd_oth[(size_t)b * n_oth + j];
+                const float *o = oth + 3 * (size_t)j;
                 ax -= g * (o[0] - ox);
                 ay -= g * (o[1] - oy);
                 az -= g * (o[2] - oz);
-            }
+            });
         }
         gout[3 * i] = ax;
         gout[3 * i + 1] = ay;

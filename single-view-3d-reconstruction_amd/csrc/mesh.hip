@@ -135,7 +135,7 @@ __device__ inline void camera_backward(const Camera &c, float X, float Y, float 
 
 using sv3d_dev::build_buckets;
 using sv3d_dev::kSortThreads;
-using sv3d_dev::next_slot;
+using sv3d_dev::for_each_slot_ascending;
 
 // Sum of 7 per-thread values over a 1024-thread block in a fixed order; thread i < 7 stores
 // total i to dst[i].
@@ -189,12 +189,10 @@ __global__ __launch_bounds__(kSortThreads) void mesh_scatter_kernel(
     for (int v = tid; v < V; v += kSortThreads) {
         const int s0 = start[v], s1 = fill[v];
         float x = 0.f, y = 0.f, z = 0.f;
-        int last = -1;
-        for (int i = s0; i < s1; ++i) {
-            last = next_slot(bucket, s0, s1, last);
-            const float *gs = g + 3 * (long)last;
+        for_each_slot_ascending(bucket, s0, s1, fb, v, V, nslots, [&](int slot) {
+            const float *gs = g + 3 * (long)slot;
             x += gs[0]; y += gs[1]; z += gs[2];
-        }
+        });
         x *= a.s0; y *= a.s1; z *= a.s2;
         float *dst = grad_values + ((long)b * V + v) * 3;
         if (PROJECT) {
@@ -283,14 +281,12 @@ __global__ __launch_bounds__(kSortThreads) void mesh_scatter_n_kernel(
     for (int v = threadIdx.x; v < V; v += kSortThreads) {
         const int s0 = start[v], s1 = fill[v];
         float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        int last = -1;
-        for (int i = s0; i < s1; ++i) {
-            last = next_slot(bucket, s0, s1, last);
-            const float *gs = g + (long)last * C;
+        for_each_slot_ascending(bucket, s0, s1, fb, v, V, nslots, [&](int slot) {
+            const float *gs = g + (long)slot * C;
 #pragma unroll
             for (int c = 0; c < 8; ++c)
                 if (c < C) a[c] += gs[c];
-        }
+        });
         float *dst = grad_values + ((long)b * V + v) * C;
 #pragma unroll
         for (int c = 0; c < 8; ++c)

@@ -114,6 +114,33 @@ def test_backward_both_sides_large_clouds(N, M):
     assert rel_err(grads[0][1].cpu(), torch.from_numpy(w2)) < GRAD_RTOL
 
 
+def test_backward_collapsed_cloud_stays_fast_and_exact():
+    """Every point of the second cloud has the same nearest neighbour (a cloud collapsed onto one
+    point next to it): one bucket holds all 8192 indices.  The walk of such a bucket is bounded by
+    a scan of the index array; the result equals the oracle's."""
+    import time
+    import sv3d
+    rng = np.random.default_rng(4)
+    a = rng.standard_normal((2, 8192, 3)).astype(np.float32)
+    b = (a[:, 17:18] + 1e-3 * rng.standard_normal((2, 8192, 3))).astype(np.float32)
+    gd1 = rng.standard_normal((2, 8192)).astype(np.float32)
+    gd2 = rng.standard_normal((2, 8192)).astype(np.float32)
+    ta = torch.from_numpy(a).cuda().requires_grad_(True)
+    tb = torch.from_numpy(b).cuda().requires_grad_(True)
+    d1, d2, i1, i2 = sv3d.chamfer_nn(ta, tb)
+    assert int((i2 == 17).sum()) == 2 * 8192
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ((d1 * torch.from_numpy(gd1).cuda()).sum() + (d2 * torch.from_numpy(gd2).cuda()).sum()).backward()
+    torch.cuda.synchronize()
+    assert time.perf_counter() - t0 < 0.5
+    w1, w2 = chamfer_oracle.backward_c(a, b, gd1, gd2, i1.cpu().numpy(), i2.cpu().numpy())
+    # points on the hull of the clump collect thousands of first-cloud points each: fp32 sums of
+    # thousands of O(1) terms against the oracle's double accumulation
+    assert rel_err(ta.grad.cpu(), torch.from_numpy(w1)) < 1e-5
+    assert rel_err(tb.grad.cpu(), torch.from_numpy(w2)) < 1e-5
+
+
 def test_reference_usage_only_dist2_and_detached_first_cloud():
     """loss_utils.py:75-88 keeps dist2.mean(); main.py:525 detaches the first cloud."""
     from nnutils import loss_utils

@@ -257,3 +257,22 @@ def test_texture_sets_shared_by_camera_hypotheses(ambient):
     assert rel_err(t_set.grad, t_cat.grad) < 1e-6          # same terms, summed in another order
     with pytest.raises(ValueError):
         r.forward(v, f, cams, tex[:1].repeat(4, 1, 1, 1).cuda())     # 4 does not divide 6
+
+
+@pytest.mark.gpu
+def test_fan_mesh_with_a_hub_vertex_in_every_face():
+    """A fan of 4000 faces around vertex 0: the hub's bucket holds a third of all corner slots, so
+    its gradient is gathered by a scan of the face array instead of the quadratic bucket walk."""
+    import sv3d
+    F = 4000
+    idx = torch.arange(F, dtype=torch.int32)
+    faces = torch.stack([torch.zeros(F, dtype=torch.int32), 1 + idx, 1 + (idx + 1) % F], 1)[None].cuda()
+    g = torch.Generator().manual_seed(0)
+    values = torch.randn(2, F + 1, 3, generator=g).cuda().requires_grad_(True)
+    w = torch.randn(2, F, 3, 3, generator=g).cuda()
+    out = sv3d.face_gather(values, faces)
+    (out * w).sum().backward()
+    ref = values.detach().clone().requires_grad_(True)
+    (ref[:, faces[0].long()] * w).sum().backward()
+    assert torch.equal(out, ref[:, faces[0].long()])
+    assert rel_err(values.grad.cpu(), ref.grad.cpu()) < 1e-6
