@@ -69,8 +69,8 @@ const char *sv3d_strerror(int status);
 int sv3d_abi_version(void);
 
 /* Byte sizes of the buffers the rasterizer calls need:
- *   face_rec_bytes    per-face setup records (and, for meshes from 2048 faces, coarse-bin face
- *                     lists) written by forward, read by backward
+ *   face_rec_bytes    per-face setup records, pixel boxes, face-group boxes (and, for meshes
+ *                     from 2048 faces, coarse-bin face lists) written by forward, read by backward
  *   pixel_saved_bytes per-raster-pixel aggregates written by forward, read by backward
  *   backward_ws_bytes scratch for backward; always 0 (the backward folds its inputs on
  *                     the fly), kept so that callers sized by this query stay valid;

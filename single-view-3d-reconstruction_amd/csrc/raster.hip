@@ -276,7 +276,8 @@ __device__ inline float cross_rounded(float ax, float ay, float bx, float by)
 // Record of face `gid` from its three camera-space corners; zref = z of the image's first corner.
 __device__ inline void setup_face(const DevParams &P, int gid, float x0, float y0, float z0, float x1,
                                   float y1, float z1, float x2, float y2, float z2, float zref,
-                                  float4 *__restrict__ rec, uint2 *__restrict__ pbox)
+                                  float4 *__restrict__ rec, uint2 *__restrict__ pbox, int &col0, int &col1,
+                                  int &row0, int &row1)
 {
     const float e0x = x1 - x0, e0y = y1 - y0;
     const float e1x = x2 - x1, e1y = y2 - y1;
@@ -297,9 +298,11 @@ __device__ inline void setup_face(const DevParams &P, int gid, float x0, float y
     const float cx1 = floorf(fminf(fmaxf((fs * bx1 + fs - 1.f) * 0.5f, -2.f), hi) + 0.01f);
     const float cy0 = ceilf(fminf(fmaxf((fs * by0 + fs - 1.f) * 0.5f, -2.f), hi) - 0.01f);
     const float cy1 = floorf(fminf(fmaxf((fs * by1 + fs - 1.f) * 0.5f, -2.f), hi) + 0.01f);
-    int col0 = max((int)cx0, 0), col1 = min((int)cx1, P.S - 1);
+    col0 = max((int)cx0, 0);
+    col1 = min((int)cx1, P.S - 1);
     int yi0 = max((int)cy0, 0), yi1 = min((int)cy1, P.S - 1);
-    int row0 = P.S - 1 - yi1, row1 = P.S - 1 - yi0;
+    row0 = P.S - 1 - yi1;
+    row1 = P.S - 1 - yi0;
     const bool finite = (bx0 == bx0) && (bx1 == bx1) && (by0 == by0) && (by1 == by1);
     // A face whose projected area is below the clamp on the determinant (a point, a segment, an
     // exactly edge-on face) has no barycentric coordinates: upstream's algebra then yields
@@ -325,15 +328,44 @@ __device__ inline void setup_face(const DevParams &P, int gid, float x0, float y
     pbox[gid] = box;
 }
 
-__global__ __launch_bounds__(kThreads) void raster_setup_kernel(
-    DevParams P, const float *__restrict__ fv, float4 *__restrict__ rec, uint2 *__restrict__ pbox)
+// The setup kernels run on a (faces, image) grid, so that a wave holds 64 consecutive faces of
+// one image: the union of their pixel boxes is stored as the box of face group f / 64.  Meshes
+// number their faces coherently (an icosphere's 64 consecutive faces cover a sixth of its
+// extent), so a tile of the forward pass can drop most groups on that one box.
+constexpr int kGroupFaces = 64;
+__host__ __device__ inline int face_groups(int F) { return (F + kGroupFaces - 1) / kGroupFaces; }
+
+__device__ inline void store_group_box(const DevParams &P, int b, int f, bool valid, int col0, int col1, int row0,
+                                       int row1, uint2 *__restrict__ gbox)
 {
-    const int gid = blockIdx.x * kThreads + threadIdx.x;
-    if (gid >= P.B * P.F) return;
-    const int b = gid / P.F;
-    const float *v = fv + (size_t)gid * 9;
-    setup_face(P, gid, v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], v[8],
-               fv[(size_t)b * P.F * 9 + 2], rec, pbox);
+    int c0 = valid ? col0 : 32767, c1 = valid ? col1 : -1, r0 = valid ? row0 : 32767, r1 = valid ? row1 : -1;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        c0 = min(c0, __shfl_xor(c0, d));
+        c1 = max(c1, __shfl_xor(c1, d));
+        r0 = min(r0, __shfl_xor(r0, d));
+        r1 = max(r1, __shfl_xor(r1, d));
+    }
+    if ((threadIdx.x & 63) == 0 && f < P.F)
+        gbox[(size_t)b * face_groups(P.F) + f / kGroupFaces] =
+            make_uint2((uint32_t)(c0 & 0xffff) | ((uint32_t)(c1 & 0xffff) << 16),
+                       (uint32_t)(r0 & 0xffff) | ((uint32_t)(r1 & 0xffff) << 16));
+}
+
+__global__ __launch_bounds__(kThreads) void raster_setup_kernel(
+    DevParams P, const float *__restrict__ fv, float4 *__restrict__ rec, uint2 *__restrict__ pbox,
+    uint2 *__restrict__ gbox)
+{
+    const int b = blockIdx.y, f = blockIdx.x * kThreads + threadIdx.x;
+    const bool valid = f < P.F;
+    int col0 = 32767, col1 = -1, row0 = 32767, row1 = -1;
+    if (valid) {
+        const int gid = b * P.F + f;
+        const float *v = fv + (size_t)gid * 9;
+        setup_face(P, gid, v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], v[8],
+                   fv[(size_t)b * P.F * 9 + 2], rec, pbox, col0, col1, row0, row1);
+    }
+    store_group_box(P, b, f, valid, col0, col1, row0, row1, gbox);
 }
 
 // Setup straight from the object-space mesh: each thread projects its face's three vertices
@@ -349,11 +381,13 @@ struct MeshArgs {
 
 __global__ __launch_bounds__(kThreads) void raster_setup_mesh_kernel(
     DevParams P, MeshArgs m, float *__restrict__ fv_out, float4 *__restrict__ rec,
-    uint2 *__restrict__ pbox)
+    uint2 *__restrict__ pbox, uint2 *__restrict__ gbox)
 {
-    const int gid = blockIdx.x * kThreads + threadIdx.x;
-    if (gid >= P.B * P.F) return;
-    const int b = gid / P.F, f = gid - b * P.F;
+    const int b = blockIdx.y, f = blockIdx.x * kThreads + threadIdx.x;
+    const bool valid = f < P.F;
+    int col0 = 32767, col1 = -1, row0 = 32767, row1 = -1;
+    if (valid) {
+    const int gid = b * P.F + f;
     const int32_t *fb = m.faces + (m.faces_batch > 1 ? (size_t)b * P.F * 3 : 0);
     const sv3d_dev::Camera c = sv3d_dev::load_camera(m.cams + (size_t)b * 7, m.offset_z);
     const float *vb = m.vertices + (size_t)b * m.V * 3;
@@ -371,7 +405,10 @@ __global__ __launch_bounds__(kThreads) void raster_setup_mesh_kernel(
 #pragma unroll
         for (int i = 0; i < 9; ++i) fv_out[(size_t)gid * 9 + i] = o[i];
     }
-    setup_face(P, gid, o[0], o[1], o[2], o[3], o[4], o[5], o[6], o[7], o[8], zref, rec, pbox);
+    setup_face(P, gid, o[0], o[1], o[2], o[3], o[4], o[5], o[6], o[7], o[8], zref, rec, pbox, col0, col1,
+               row0, row1);
+    }
+    store_group_box(P, b, f, valid, col0, col1, row0, row1, gbox);
 }
 
 __device__ inline void unpack_box(uint2 b, int &col0, int &col1, int &row0, int &row1)
@@ -467,9 +504,11 @@ __global__ __launch_bounds__(kThreads) void raster_coarse_kernel(
 // states through LDS at the end -- the kernel's span at small batches is its longest single wave
 // (a silhouette-ring block with ~60 faces), and this halves it.
 template <int MODE, int SPLIT, bool LO, bool COARSE>
-__global__ __launch_bounds__(kThreads * SPLIT) void raster_forward_kernel(
+__global__ __launch_bounds__(kThreads * SPLIT)
+__attribute__((amdgpu_waves_per_eu(MODE == SV3D_TEX_VERTEX8 ? 7 : 8))) void raster_forward_kernel(
     DevParams P, const float4 *__restrict__ rec, const uint2 *__restrict__ pbox,
-    const float *__restrict__ tex, float *__restrict__ rgba, float *__restrict__ saved, CoarseBins CB)
+    const uint2 *__restrict__ gbox, const float *__restrict__ tex, float *__restrict__ rgba,
+    float *__restrict__ saved, CoarseBins CB)
 {
     constexpr int NT = kThreads * SPLIT;        // threads per workgroup
     constexpr int NW = 4 * SPLIT;               // waves per workgroup
@@ -635,6 +674,51 @@ __global__ __launch_bounds__(kThreads * SPLIT) void raster_forward_kernel(
     SV3D_STAMP(0);
     for (int fbase = 0; fbase < ncand; fbase += 64 * 64) {
         const int nmask = (min(ncand - fbase, 64 * 64) + 63) >> 6;  // at most 64 masks per pass
+        if (!COARSE) {
+            // Face groups first: lane l tests the box of group l (the 64 faces of mask l) against
+            // the tile; only the groups that touch it have their faces' boxes loaded, dealt out to
+            // the waves in turn, up to four per wave and trip so that the loads overlap.  A tile no
+            // group touches is done after this one small load.
+            const uint2 *gbox_b = gbox + (size_t)b * face_groups(F) + (fbase >> 6);
+            bool touch = false;
+            if (lane < nmask) {
+                int c0, c1, r0, r1;
+                unpack_box(gbox_b[lane], c0, c1, r0, r1);
+                touch = !(c1 < tile_c0 || c0 > tc1 || r1 < tile_r0 || r0 > tr1);
+            }
+            unsigned long long todo = __ballot(touch);
+            if (lane < nmask && !touch && (lane & (NW - 1)) == wave) s_mask[lane] = 0ull;
+            while (todo != 0ull) {                                      // wave-uniform
+                int sel[4] = {-1, -1, -1, -1};
+                int ord = 0, got = 0;
+                unsigned long long bits = todo;
+                for (; bits != 0ull && ord < 4 * NW; bits &= bits - 1ull, ++ord) {
+                    if ((ord & (NW - 1)) == wave) {
+                        const int mi = __builtin_ctzll(bits);
+                        if (got == 0) sel[0] = mi; else if (got == 1) sel[1] = mi;
+                        else if (got == 2) sel[2] = mi; else sel[3] = mi;
+                        ++got;
+                    }
+                }
+                todo = bits;                                            // the groups of later trips
+                uint2 bx[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int cand = fbase + sel[k] * 64 + lane;
+                    bx[k] = (sel[k] >= 0 && cand < ncand) ? pbox_b[cand] : make_uint2(0xffff7fffu, 0xffff7fffu);
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (sel[k] >= 0) {                                  // wave-uniform
+                        int c0, c1, r0, r1;
+                        unpack_box(bx[k], c0, c1, r0, r1);
+                        const bool hit = !(c1 < tile_c0 || c0 > tc1 || r1 < tile_r0 || r0 > tr1);
+                        const unsigned long long mask = __ballot(hit);
+                        if (lane == 0) s_mask[sel[k]] = mask;
+                    }
+                }
+            }
+        } else
         for (int m0 = wave; m0 < nmask; m0 += 8 * NW) {             // eight masks per wave per trip
             uint2 bx[8];
 #pragma unroll
@@ -1186,6 +1270,7 @@ int make_dev_params(const sv3d_raster_params *p, DevParams &d)
 }
 
 inline size_t rec_floats(const DevParams &d) { return (size_t)d.B * d.F * kRec; }
+inline size_t group_boxes(const DevParams &d) { return (size_t)d.B * face_groups(d.F); }
 inline int saved_per_pixel(const DevParams &d)
 {
     return d.mode == SV3D_TEX_NONE ? 1 : (d.mode == SV3D_TEX_VERTEX8 ? 12 : 6);
@@ -1223,7 +1308,8 @@ extern "C" int sv3d_raster_sizes(const sv3d_raster_params *p, size_t *face_rec_b
     if (st != SV3D_OK) return st;
     const size_t pix = (size_t)d.B * d.S * d.S * saved_per_pixel(d) * sizeof(float);
     if (face_rec_bytes)
-        *face_rec_bytes = rec_floats(d) * sizeof(float) + (size_t)d.B * d.F * sizeof(uint2) + coarse_bytes(d);
+        *face_rec_bytes = rec_floats(d) * sizeof(float) + ((size_t)d.B * d.F + group_boxes(d)) * sizeof(uint2) +
+                          coarse_bytes(d);
     if (pixel_saved_bytes) *pixel_saved_bytes = pix;
     if (backward_ws_bytes) *backward_ws_bytes = backward_ws_need(d);
     return SV3D_OK;
@@ -1253,16 +1339,17 @@ int raster_forward_impl(const sv3d_raster_params *p, const float *face_vertices,
     float4 *rec = static_cast<float4 *>(face_rec);
     uint2 *pbox = reinterpret_cast<uint2 *>(static_cast<float *>(face_rec) + rec_floats(d));
     const int nf = d.B * d.F;
+    uint2 *gbox = pbox + nf;                        // [B][face_groups(F)], then the coarse bins
+    const dim3 sgrid((d.F + kThreads - 1) / kThreads, d.B);
     if (mesh) {
         MeshArgs m;
         m.vertices = mesh->vertices; m.cams = mesh->cams; m.faces = mesh->faces;
         m.V = mesh->num_vertices; m.faces_batch = mesh->faces_batch; m.offset_z = mesh->offset_z;
         m.a = {mesh->scale[0], mesh->scale[1], mesh->scale[2], mesh->shift[0], mesh->shift[1], mesh->shift[2]};
-        hipLaunchKernelGGL(raster_setup_mesh_kernel, dim3((nf + kThreads - 1) / kThreads), dim3(kThreads), 0,
-                           s, d, m, const_cast<float *>(face_vertices), rec, pbox);
+        hipLaunchKernelGGL(raster_setup_mesh_kernel, sgrid, dim3(kThreads), 0, s, d, m,
+                           const_cast<float *>(face_vertices), rec, pbox, gbox);
     } else {
-        hipLaunchKernelGGL(raster_setup_kernel, dim3((nf + kThreads - 1) / kThreads), dim3(kThreads), 0, s,
-                           d, face_vertices, rec, pbox);
+        hipLaunchKernelGGL(raster_setup_kernel, sgrid, dim3(kThreads), 0, s, d, face_vertices, rec, pbox, gbox);
     }
     const int tiles = (d.S + kTile - 1) / kTile;
     dim3 grid((unsigned)tiles * tiles * d.B);
@@ -1271,7 +1358,7 @@ int raster_forward_impl(const sv3d_raster_params *p, const float *face_vertices,
     const bool coarse = coarse_enabled(d);
     if (coarse) {
         const int bx = coarse_bins_x(d), nbins = bx * bx, cap = coarse_cap(d);
-        int *count = reinterpret_cast<int *>(pbox + nf);
+        int *count = reinterpret_cast<int *>(gbox + group_boxes(d));
         unsigned short *list = reinterpret_cast<unsigned short *>(count + (size_t)d.B * nbins);
         hipLaunchKernelGGL(raster_coarse_kernel, dim3((unsigned)(d.B * nbins)), dim3(kThreads), 0, s, d, pbox,
                            list, count, bx, nbins, cap);
@@ -1284,7 +1371,7 @@ int raster_forward_impl(const sv3d_raster_params *p, const float *face_vertices,
     const bool lo = (d.S & (d.S - 1)) != 0;
 #define SV3D_LAUNCH_FWD2(M, SP, LO_, CO_)                                                              \
     hipLaunchKernelGGL((raster_forward_kernel<M, SP, LO_, CO_>), grid, dim3(SP * kThreads), 0, s, d, rec,  \
-                       pbox, textures, rgba_out, saved, cb)
+                       pbox, gbox, textures, rgba_out, saved, cb)
 #define SV3D_LAUNCH_FWD(M)                                                                             \
     do {                                                                                               \
         if (coarse && lo) SV3D_LAUNCH_FWD2(M, 1, true, true);                                          \

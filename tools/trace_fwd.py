@@ -68,6 +68,11 @@ print("workgroups traced", n, "kernel span %.1f us" % end.max())
 print("wave start: min %.1f p50 %.1f p99 %.1f max %.1f us" % (start.min(), np.median(start), np.percentile(start, 99), start.max()))
 print("wave dur  : mean %.1f p50 %.1f p90 %.1f p99 %.1f max %.1f us" % (dur.mean(), np.median(dur), np.percentile(dur, 90), np.percentile(dur, 99), dur.max()))
 print("visits/wave: mean %.1f max %d ; correlation dur~visits %.2f" % (visits.mean(), visits.max(), np.corrcoef(dur.ravel(), visits.ravel())[0, 1]))
+wg_sum, wg_max = visits.sum(1), visits.max(1)
+busy = wg_max > 0
+print("visits per workgroup: mean %.1f; sum / (waves x max) over non-empty workgroups: %.2f (1 = waves of a workgroup evenly loaded)"
+      % (wg_sum.mean(), (wg_sum[busy] / (visits.shape[1] * wg_max[busy])).mean()))
+print("sum over workgroups of waves x max visits vs sum of visits: %.2f" % ((visits.shape[1] * wg_max).sum() / max(wg_sum.sum(), 1)))
 z = visits.ravel() == 0
 print("waves with zero visits: %.0f%%, their mean dur %.2f us" % (100 * z.mean(), dur.ravel()[z].mean() if z.any() else 0))
 fit = np.polyfit(visits.ravel(), dur.ravel(), 1)
