@@ -208,7 +208,8 @@ def test_c_abi_argument_validation_without_gpu():
     from sv3d import _lib
     p = _lib.make_params(8, 1280, 256, 1, 0, 1, True, (0, 0, 0), 1, 100, 1e-3, 1e-4, 1e-10, 1e-4)
     rec, saved, ws = _lib.raster_sizes(p)
-    assert rec == 8 * 1280 * (32 * 4 + 8) and saved == 8 * 256 * 256 * 4 and ws == 0
+    # per face a 128-byte record and an 8-byte pixel box, per group of 64 faces an 8-byte box
+    assert rec == 8 * 1280 * (32 * 4 + 8) + 8 * 20 * 8 and saved == 8 * 256 * 256 * 4 and ws == 0
     p.texture_mode = 1
     p.texture_res = 6
     assert _lib.raster_sizes(p)[1:] == (8 * 256 * 256 * 6 * 4, 0)        # no backward scratch in any mode
