@@ -1367,7 +1367,7 @@ int raster_forward_impl(const sv3d_raster_params *p, const float *face_vertices,
     if (ev_start) (void)hipEventRecord(ev_start, s);
     // two waves per block while the grid is small enough that single waves set the kernel's span;
     // the remainder-carrying variants when S is not a power of two
-    const bool split = (long)tiles * tiles * d.B <= 4096;
+    const bool split = (long)tiles * tiles * d.B <= 2048;      // measured: 12 and 16 images of 256^2 are faster unsplit
     const bool lo = (d.S & (d.S - 1)) != 0;
 #define SV3D_LAUNCH_FWD2(M, SP, LO_, CO_)                                                              \
     hipLaunchKernelGGL((raster_forward_kernel<M, SP, LO_, CO_>), grid, dim3(SP * kThreads), 0, s, d, rec,  \

@@ -34,6 +34,13 @@ CONFIGS = {
     "ref_mask_b8": (8, 256, True, 3, 1e-5, "none", 1),
     "ref_rgb_b8": (8, 256, True, 3, 1e-5, "surface", 6),
     "ref_rgb_b16": (16, 256, True, 3, 1e-5, "surface", 6),
+    # batch sweep at the benchmark configuration: either side of the kernels' launch-size thresholds
+    "c2b2": (2, 256, False, 3, 1e-4, "none", 1),
+    "c2b4": (4, 256, False, 3, 1e-4, "none", 1),
+    "c2b12": (12, 256, False, 3, 1e-4, "none", 1),
+    "c2b16": (16, 256, False, 3, 1e-4, "none", 1),
+    "c2b20": (20, 256, False, 3, 1e-4, "none", 1),
+    "c2b32": (32, 256, False, 3, 1e-4, "none", 1),
 }
 
 
