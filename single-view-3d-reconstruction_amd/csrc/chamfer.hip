@@ -194,7 +194,7 @@ __global__ __launch_bounds__(kThreads) void chamfer_grad_kernel(
     const float ox = own[3 * ic], oy = own[3 * ic + 1], oz = own[3 * ic + 2];
     float ax = 0.f, ay = 0.f, az = 0.f;
     if (gd_own != nullptr) {
-        const int j = idx_own[ic];
+        const int j = min(max(idx_own[ic], 0), n_oth - 1);     // a foreign index array cannot fault
         const float g = 2.f * gd_own[(size_t)b * n_own + ic];
         ax = g * (ox - oth[3 * j]);
         ay = g * (oy - oth[3 * j + 1]);
@@ -259,7 +259,7 @@ __global__ __launch_bounds__(sv3d_dev::kSortThreads) void chamfer_grad_sorted_ke
         const float ox = own[3 * i], oy = own[3 * i + 1], oz = own[3 * i + 2];
         float ax = 0.f, ay = 0.f, az = 0.f;
         if (gd_own != nullptr) {
-            const int j = idx_own[i];
+            const int j = min(max(idx_own[i], 0), n_oth - 1);
             const float g = 2.f * gd_own[(size_t)b * n_own + i];
             ax = g * (ox - oth[3 * j]);
             ay = g * (oy - oth[3 * j + 1]);
