@@ -51,6 +51,8 @@ def add_training_flags(parser=None):
     p.add_argument('--grad_clip', type=float, default=0.1)
     p.add_argument('--epoch_fraction', type=float, default=0.1)
     p.add_argument('--amp', type=int, default=1)
+    p.add_argument('--amp_dtype', choices=['fp16', 'bf16'], default='fp16',
+                   help='autocast type; the reference uses fp16 with a GradScaler (train_utils.py:182-214)')
     p.add_argument('--seed', type=int, default=0)
     return p
 
@@ -213,7 +215,9 @@ class Trainer(object):
         if self._second_optimizer():
             self.optimizer_2.zero_grad(set_to_none=True)
         use_amp = self.device.type == 'cuda' and bool(getattr(opts, 'amp', 1))
-        with torch.autocast(device_type=self.device.type, enabled=use_amp):
+        amp_dtype = torch.bfloat16 if getattr(opts, 'amp_dtype', 'fp16') == 'bf16' else torch.float16
+        with torch.autocast(device_type=self.device.type, dtype=amp_dtype if self.device.type == 'cuda' else None,
+                            enabled=use_amp):
             self.forward(total_steps)
         # the reference's smoothed loss (:194), kept on the device: no host sync per step
         self.smoothed_total_loss = self.smoothed_total_loss * 0.99 + 0.01 * self.total_loss.detach().float()
