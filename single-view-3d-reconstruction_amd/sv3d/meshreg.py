@@ -10,7 +10,7 @@ import torch
 from torch import Tensor
 
 from . import _lib as L
-from .ops import _f32c, _plain, _ptr, _stream
+from .ops import _f32c, _on, _plain, _ptr, _stream
 
 
 # ----------------------------------------------------------------------------------------------
@@ -99,7 +99,7 @@ def _laplacian_launch(vertices, row_start, nbr):
     B, V = x.shape[0], x.shape[1]
     if row_start.numel() != V + 1:
         raise ValueError("row_start must hold V + 1 = %d entries, got %d" % (V + 1, row_start.numel()))
-    with torch.cuda.device(x.device):
+    with _on(x.device):
         loss = torch.empty((B,), dtype=torch.float32, device=x.device)
         grad = torch.empty_like(x)
         L.check(L.lib().sv3d_laplacian_loss(_ptr(x), _ptr(row_start), _ptr(nbr), B, V, _ptr(loss), _ptr(grad),
@@ -128,7 +128,7 @@ def _flatten_launch(vertices, quads, inc_start, inc, eps):
         raise ValueError("quads must be a non-empty [E,4] tensor, got %s" % (tuple(quads.shape),))
     if inc_start.numel() != V + 1 or inc.numel() != 4 * E:
         raise ValueError("incidence tables must hold V + 1 and 4 E entries")
-    with torch.cuda.device(x.device):
+    with _on(x.device):
         loss = torch.empty((B,), dtype=torch.float32, device=x.device)
         grad = torch.empty_like(x)
         L.check(L.lib().sv3d_flatten_loss(_ptr(x), _ptr(quads), _ptr(inc_start), _ptr(inc), B, V, E, float(eps),
@@ -184,7 +184,7 @@ def mesh_spmv_op(x: Tensor, values: Tensor, row_start: Tensor, col: Tensor,
         raise ValueError("values must be [B or 1, nnz=%d], got %s" % (nnz, tuple(vals.shape)))
     if row_start.numel() != V + 1:
         raise ValueError("row_start must hold V + 1 = %d entries, got %d" % (V + 1, row_start.numel()))
-    with torch.cuda.device(xs.device):
+    with _on(xs.device):
         y = torch.empty_like(xs)
         L.check(L.lib().sv3d_mesh_spmv(_ptr(vals), _ptr(row_start), _ptr(col), _ptr(xs), B, V, nnz, vals.shape[0],
                                        _ptr(y), _stream(xs)), "sv3d_mesh_spmv")

@@ -26,12 +26,38 @@ def _ptr(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None and t.numel() > 0 else None
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream(t):
+    """The current stream of the tensor's device as a raw handle."""
+    if _raw_stream is not None:
+        return ctypes.c_void_p(_raw_stream(t.device.index))
     return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
 
 
 def _f32c(t):
-    return t.detach().to(torch.float32).contiguous()
+    """Detached fp32 contiguous view (a copy only when the tensor is not that already)."""
+    t = t.detach()
+    if t.dtype is not torch.float32:
+        t = t.to(torch.float32)
+    return t if t.is_contiguous() else t.contiguous()
+
+
+class _NoGuard:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NO_GUARD = _NoGuard()
+
+
+def _on(device):
+    """Device guard for allocations and launches; free when `device` is the current one."""
+    return _NO_GUARD if device.index == torch.cuda.current_device() else torch.cuda.device(device)
 
 
 def _params(fv, raster_size, aa, texture_mode, texture_res, double_side, background,
@@ -106,7 +132,7 @@ def soft_rasterize_op(face_vertices: Tensor, textures: Optional[Tensor], raster_
                                     near, far, eps, sigma, dist_eps, gamma), tex)
     rec_b, saved_b, _ = L.raster_sizes(p)
     H = raster_size // aa
-    with torch.cuda.device(fv.device):
+    with _on(fv.device):
         rgba = torch.empty((fv.shape[0], _channels(texture_mode), H, H), dtype=torch.float32, device=fv.device)
         rec = torch.empty(rec_b // 4, dtype=torch.float32, device=fv.device)
         saved = torch.empty(saved_b // 4, dtype=torch.float32, device=fv.device)
@@ -141,7 +167,7 @@ def soft_rasterize_backward_op(grad_rgba: Tensor, textures: Optional[Tensor], fa
     p = _with_texture_batch(L.make_params(batch, num_faces, raster_size, aa, texture_mode, texture_res,
                                           double_side, background, near, far, eps, sigma, dist_eps, gamma), tex)
     _, _, ws_b = L.raster_sizes(p)
-    with torch.cuda.device(g.device):
+    with _on(g.device):
         gfv = torch.empty((batch, num_faces, 3, 3), dtype=torch.float32, device=g.device)
         gtex = _grad_textures_buffer(tex, batch) if (tex is not None and need_textures) else \
             torch.empty(0, dtype=torch.float32, device=g.device)
@@ -249,7 +275,7 @@ def chamfer_nn_op(xyz1: Tensor, xyz2: Tensor) -> Tuple[Tensor, Tensor, Tensor, T
     _check_clouds(xyz1, xyz2)
     a, b = _f32c(xyz1), _f32c(xyz2)
     B, N, M = a.shape[0], a.shape[1], b.shape[1]
-    with torch.cuda.device(a.device):
+    with _on(a.device):
         d1 = torch.empty((B, N), dtype=torch.float32, device=a.device)
         d2 = torch.empty((B, M), dtype=torch.float32, device=a.device)
         i1 = torch.empty((B, N), dtype=torch.int32, device=a.device)
@@ -274,7 +300,7 @@ def chamfer_nn_backward_op(xyz1: Tensor, xyz2: Tensor, grad_dist1: Optional[Tens
     B, N, M = a.shape[0], a.shape[1], b.shape[1]
     gd1 = _f32c(grad_dist1) if grad_dist1 is not None else None
     gd2 = _f32c(grad_dist2) if grad_dist2 is not None else None
-    with torch.cuda.device(a.device):
+    with _on(a.device):
         g1 = torch.empty_like(a) if need1 else torch.empty(0, dtype=torch.float32, device=a.device)
         g2 = torch.empty_like(b) if need2 else torch.empty(0, dtype=torch.float32, device=a.device)
         L.check(L.lib().sv3d_chamfer_backward(_ptr(a), _ptr(b), B, N, M, _ptr(gd1), _ptr(gd2),
@@ -326,7 +352,7 @@ def face_gather_op(values: Tensor, faces: Tensor, scale: List[float], shift: Lis
     v = _f32c(values)
     f = faces.contiguous()
     B, V, F = v.shape[0], v.shape[1], f.shape[1]
-    with torch.cuda.device(v.device):
+    with _on(v.device):
         out = torch.empty((B, F, 3, 3), dtype=torch.float32, device=v.device)
         L.check(L.lib().sv3d_face_gather(_ptr(v), _ptr(f), B, V, F, f.shape[0], L.float3(scale),
                                          L.float3(shift), _ptr(out), _stream(v)), "sv3d_face_gather")
@@ -342,7 +368,7 @@ def _(values, faces, scale, shift):
 def face_scatter_op(grad_out: Tensor, faces: Tensor, num_vertices: int, scale: List[float]) -> Tensor:
     g = _f32c(grad_out)
     B, F = g.shape[0], g.shape[1]
-    with torch.cuda.device(g.device):
+    with _on(g.device):
         out = torch.empty((B, num_vertices, 3), dtype=torch.float32, device=g.device)
         L.check(L.lib().sv3d_face_scatter(_ptr(g), _ptr(faces), B, num_vertices, F, faces.shape[0],
                                           L.float3(scale), _ptr(out), _stream(g)), "sv3d_face_scatter")
@@ -396,7 +422,7 @@ def project_gather_op(vertices: Tensor, cams: Tensor, faces: Tensor, offset_z: f
     _check_mesh(vertices, cams, faces)
     v, c, f = _f32c(vertices), _f32c(cams), faces.contiguous()
     B, F = v.shape[0], f.shape[1]
-    with torch.cuda.device(v.device):
+    with _on(v.device):
         out = torch.empty((B, F, 3, 3), dtype=torch.float32, device=v.device)
         m = L.make_mesh_input(v, c, f, offset_z, scale, shift)
         L.check(L.lib().sv3d_project_gather(ctypes.byref(m), B, F, _ptr(out), _stream(v)),
@@ -414,7 +440,7 @@ def project_scatter_op(grad_out: Tensor, vertices: Tensor, cams: Tensor, faces: 
                        offset_z: float, scale: List[float]) -> Tuple[Tensor, Tensor]:
     g, v, c = _f32c(grad_out), _f32c(vertices), _f32c(cams)
     B, F = g.shape[0], g.shape[1]
-    with torch.cuda.device(g.device):
+    with _on(g.device):
         gv = torch.empty_like(v)
         gc = torch.empty_like(c)
         m = L.make_mesh_input(v, c, faces, offset_z, scale, (0.0, 0.0, 0.0))
@@ -474,7 +500,7 @@ def render_op(vertices: Tensor, cams: Tensor, faces: Tensor, textures: Optional[
                                           background, near, far, eps, sigma, dist_eps, gamma), tex)
     rec_b, saved_b, _ = L.raster_sizes(p)
     H = raster_size // aa
-    with torch.cuda.device(v.device):
+    with _on(v.device):
         rgba = torch.empty((B, _channels(texture_mode), H, H), dtype=torch.float32, device=v.device)
         rec = torch.empty(rec_b // 4, dtype=torch.float32, device=v.device)
         saved = torch.empty(saved_b // 4, dtype=torch.float32, device=v.device)
@@ -511,7 +537,7 @@ def render_backward_op(grad_rgba: Tensor, vertices: Tensor, cams: Tensor, faces:
     p = _with_texture_batch(L.make_params(B, F, raster_size, aa, texture_mode, texture_res, double_side,
                                           background, near, far, eps, sigma, dist_eps, gamma), tex)
     _, _, ws_b = L.raster_sizes(p)
-    with torch.cuda.device(g.device):
+    with _on(g.device):
         gfv = torch.empty((B, F, 3, 3), dtype=torch.float32, device=g.device)
         gtex = _grad_textures_buffer(tex, B) if (tex is not None and need_textures) else \
             torch.empty(0, dtype=torch.float32, device=g.device)
@@ -658,7 +684,7 @@ class _RenderFn(torch.autograd.Function):
         _with_texture_batch(p, tex)
         B, S, aa = key[0], key[2], key[3]
         dev = x.device
-        with torch.cuda.device(dev):
+        with _on(dev):
             rgba = torch.empty((B, _channels(key[4]), S // aa, S // aa), dtype=torch.float32, device=dev)
             rec = torch.empty(rec_b // 4, dtype=torch.float32, device=dev)
             saved = torch.empty(saved_b // 4, dtype=torch.float32, device=dev)
@@ -684,7 +710,7 @@ class _RenderFn(torch.autograd.Function):
         p, _, _ = _cached_params(key)
         g = _f32c(grad_rgba)
         need_tex = ctx.needs_input_grad[3]
-        with torch.cuda.device(g.device):
+        with _on(g.device):
             if ctx.has_mesh:
                 x, c, faces, rec, saved, tex = ctx.saved_tensors
                 gfv, gtex = _raster_backward_call(p, g, tex, rec, saved, need_tex, key[0], key[1])
@@ -706,7 +732,7 @@ class _ChamferFn(torch.autograd.Function):
         _check_clouds(xyz1, xyz2)
         a, b = _f32c(xyz1), _f32c(xyz2)
         B, N, M = a.shape[0], a.shape[1], b.shape[1]
-        with torch.cuda.device(a.device):
+        with _on(a.device):
             d1 = torch.empty((B, N), dtype=torch.float32, device=a.device)
             d2 = torch.empty((B, M), dtype=torch.float32, device=a.device)
             i1 = torch.empty((B, N), dtype=torch.int32, device=a.device)
@@ -727,7 +753,7 @@ class _ChamferFn(torch.autograd.Function):
         B, N, M = a.shape[0], a.shape[1], b.shape[1]
         gd1 = _f32c(gd1) if gd1 is not None else None
         gd2 = _f32c(gd2) if gd2 is not None else None
-        with torch.cuda.device(a.device):
+        with _on(a.device):
             g1 = torch.empty_like(a) if need1 else None
             g2 = torch.empty_like(b) if need2 else None
             L.check(L.lib().sv3d_chamfer_backward(_ptr(a), _ptr(b), B, N, M, _ptr(gd1), _ptr(gd2), _ptr(i1),
@@ -746,7 +772,7 @@ def face_gather_n_op(values: Tensor, faces: Tensor) -> Tensor:
         raise ValueError("faces must be int32 [B or 1,F,3], got %s %s" % (faces.dtype, tuple(faces.shape)))
     v, f = _f32c(values), faces.contiguous()
     B, V, C, F = v.shape[0], v.shape[1], v.shape[2], f.shape[1]
-    with torch.cuda.device(v.device):
+    with _on(v.device):
         out = torch.empty((B, F, 3, C), dtype=torch.float32, device=v.device)
         L.check(L.lib().sv3d_face_gather_n(_ptr(v), _ptr(f), B, V, F, f.shape[0], C, _ptr(out), _stream(v)),
                 "sv3d_face_gather_n")
@@ -762,7 +788,7 @@ def _(values, faces):
 def face_scatter_n_op(grad_out: Tensor, faces: Tensor, num_vertices: int) -> Tensor:
     g = _f32c(grad_out)
     B, F, C = g.shape[0], g.shape[1], g.shape[3]
-    with torch.cuda.device(g.device):
+    with _on(g.device):
         out = torch.empty((B, num_vertices, C), dtype=torch.float32, device=g.device)
         L.check(L.lib().sv3d_face_scatter_n(_ptr(g), _ptr(faces), B, num_vertices, F, faces.shape[0], C,
                                             _ptr(out), _stream(g)), "sv3d_face_scatter_n")

@@ -7,7 +7,7 @@ import torch
 from torch import Tensor
 
 from . import _lib as L
-from .ops import _f32c, _plain, _ptr, _stream
+from .ops import _f32c, _on, _plain, _ptr, _stream
 
 MAX_CHANNELS = 4
 
@@ -26,7 +26,7 @@ def _sample_launch(images, flow):
     img, fl = _f32c(images), _f32c(flow)
     B, C, H, W = img.shape
     N = fl.shape[1]
-    with torch.cuda.device(img.device):
+    with _on(img.device):
         out = torch.empty((B, N, C), dtype=torch.float32, device=img.device)
         L.check(L.lib().sv3d_texture_sample(_ptr(img), _ptr(fl), B, C, H, W, N, _ptr(out), _stream(img)),
                 "sv3d_texture_sample")
@@ -37,7 +37,7 @@ def _sample_backward_launch(images, flow, grad_out):
     img, fl, g = _f32c(images), _f32c(flow), _f32c(grad_out)
     B, C, H, W = img.shape
     N = fl.shape[1]
-    with torch.cuda.device(img.device):
+    with _on(img.device):
         grad_flow = torch.empty_like(fl)
         L.check(L.lib().sv3d_texture_sample_backward(_ptr(img), _ptr(fl), _ptr(g), B, C, H, W, N, _ptr(grad_flow),
                                                      _stream(img)), "sv3d_texture_sample_backward")
@@ -114,7 +114,7 @@ def distance_transform_op(masks: Tensor, barrier: bool, k: float) -> Tensor:
         raise ValueError("masks must be a non-empty [B,H,W] tensor, got %s" % (tuple(masks.shape),))
     m = _f32c(masks)
     B, H, W = m.shape
-    with torch.cuda.device(m.device):
+    with _on(m.device):
         out = torch.empty_like(m)
         nbytes = ctypes.c_size_t()
         L.check(L.lib().sv3d_distance_transform_workspace(B, H, W, ctypes.byref(nbytes)),
