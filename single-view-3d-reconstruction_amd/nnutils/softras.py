@@ -75,17 +75,18 @@ class SoftNeuralRenderer(torch.nn.Module):
     def _forward_fused(self, vertices, faces, cams, textures, scale, shift):
         """The renderer call with camera, flip, depth shift, gather and face setup inside the
         HIP ops (one launch) instead of some twenty elementwise launches."""
-        rgba = self._rgba_fused(vertices, faces, cams, textures, scale, shift)
-        return rgba[:, -1] if textures is None else rgba[:, :3]
+        if textures is None:
+            return self._rgba_fused(vertices, faces, cams, None, scale, shift, alpha_only=True)
+        return self._rgba_fused(vertices, faces, cams, textures, scale, shift)[:, :3]
 
-    def _rgba_fused(self, vertices, faces, cams, textures, scale, shift):
+    def _rgba_fused(self, vertices, faces, cams, textures, scale, shift, alpha_only=False):
         r = self.renderer.rasterizer
         kw = dict(offset_z=self.offset_z, scale=scale, shift=shift, anti_aliasing=r.anti_aliasing,
                   background_color=r.background_color, near=r.near, far=r.far, eps=r.eps,
                   sigma_val=r.sigma_val, dist_eps=r.dist_eps, gamma_val=r.gamma_val, fill_back=r.fill_back)
         if textures is None:
             self.mask_only = True
-            return sv3d.render(vertices, cams, faces, None, r.image_size, **kw)
+            return sv3d.render(vertices, cams, faces, None, r.image_size, alpha_only=alpha_only, **kw)
         self.mask_only = False
         if self.part_seg:
             self.renderer.set_texture_mode('vertex')

@@ -252,7 +252,7 @@ def soft_rasterize(face_vertices, textures=None, image_size=256, *, anti_aliasin
                bool(fill_back), tuple(float(c) for c in background_color), float(near), float(far),
                float(eps), float(sigma_val), float(dist_eps), float(gamma_val))
         return _RenderFn.apply(face_vertices, None, None, textures if mode != L.SV3D_TEX_NONE else None,
-                               None, key)
+                               None, key, False)
     rgba, _, _ = soft_rasterize_op(face_vertices, textures, int(image_size) * aa, aa, mode, res,
                                    bool(fill_back), [float(c) for c in background_color],
                                    float(near), float(far), float(eps), float(sigma_val),
@@ -592,7 +592,7 @@ render_op.register_autograd(_render_backward, setup_context=_render_setup_contex
 def render(vertices, cams, faces, textures=None, image_size=256, *, offset_z=0.0,
            scale=(1.0, 1.0, 1.0), shift=(0.0, 0.0, 0.0), anti_aliasing=False, texture_type="surface",
            background_color=(0.0, 0.0, 0.0), near=1.0, far=100.0, eps=1e-3, sigma_val=1e-5,
-           dist_eps=1e-10, gamma_val=1e-4, fill_back=True):
+           dist_eps=1e-10, gamma_val=1e-4, fill_back=True, alpha_only=False):
     """`project_gather` + `soft_rasterize` as one op: RGBA [B,4,image_size,image_size] of the mesh
     (vertices [B,V,3] object space, faces [B or 1,F,3]) seen through `cams` [B,7].  `textures` are
     per face as for `soft_rasterize` ([B,F,R*R,3] or per-corner [B,F,3,3]).  Differentiable with
@@ -622,12 +622,12 @@ def render(vertices, cams, faces, textures=None, image_size=256, *, offset_z=0.0
                float(sigma_val), float(dist_eps), float(gamma_val))
         mesh_args = (float(offset_z), tuple(float(v) for v in scale), tuple(float(v) for v in shift))
         return _RenderFn.apply(vertices, cams, f32, textures if mode != L.SV3D_TEX_NONE else None,
-                               mesh_args, key)
+                               mesh_args, key, bool(alpha_only))
     rgba, _, _ = render_op(vertices, cams, f32, textures, float(offset_z),
                            [float(s) for s in scale], [float(s) for s in shift], int(image_size) * aa, aa,
                            mode, res, bool(fill_back), [float(c) for c in background_color], float(near),
                            float(far), float(eps), float(sigma_val), float(dist_eps), float(gamma_val))
-    return rgba
+    return rgba[:, -1] if alpha_only else rgba
 
 
 # ---- eager fast path ------------------------------------------------------------------------
@@ -676,7 +676,7 @@ class _RenderFn(torch.autograd.Function):
     else face_vertices -> sv3d_raster_forward."""
 
     @staticmethod
-    def forward(ctx, geom, cams, faces, textures, mesh_args, key):
+    def forward(ctx, geom, cams, faces, textures, mesh_args, key, alpha_only):
         # geom: vertices [B,V,3] when cams is given, else face_vertices [B,F,3,3]
         x = _f32c(geom)
         tex = _f32c(textures) if key[4] != L.SV3D_TEX_NONE else None
@@ -700,15 +700,27 @@ class _RenderFn(torch.autograd.Function):
                                                     _ptr(saved), _stream(x)), "sv3d_raster_forward")
                 ctx.save_for_backward(rec, saved, tex)
         ctx.key, ctx.mesh_args, ctx.has_mesh = key, mesh_args, cams is not None
+        ctx.alpha_only = alpha_only
         ctx.dtypes = (geom.dtype, cams.dtype if cams is not None else None,
                       textures.dtype if textures is not None else None)
-        return rgba
+        # alpha_only: the silhouette plane itself is the output, so that autograd hands its gradient
+        # straight back instead of building a zero-filled RGBA gradient around it
+        return rgba[:, -1] if alpha_only else rgba
 
     @staticmethod
     def backward(ctx, grad_rgba):
         key = ctx.key
         p, _, _ = _cached_params(key)
-        g = _f32c(grad_rgba)
+        if ctx.alpha_only:
+            # only the alpha plane of the gradient is read when there are no colours
+            full = torch.empty((key[0], _channels(key[4]), key[2] // key[3], key[2] // key[3]),
+                               dtype=torch.float32, device=grad_rgba.device)
+            full[:, -1].copy_(grad_rgba)
+            if key[4] != L.SV3D_TEX_NONE:
+                full[:, :-1].zero_()
+            g = full
+        else:
+            g = _f32c(grad_rgba)
         need_tex = ctx.needs_input_grad[3]
         with _on(g.device):
             if ctx.has_mesh:
@@ -723,7 +735,7 @@ class _RenderFn(torch.autograd.Function):
                 rec, saved, tex = ctx.saved_tensors
                 gfv, gtex = _raster_backward_call(p, g, tex, rec, saved, need_tex, key[0], key[1])
                 ggeom, gcams = gfv.to(ctx.dtypes[0]), None
-        return ggeom, gcams, None, (gtex.to(ctx.dtypes[2]) if gtex is not None else None), None, None
+        return ggeom, gcams, None, (gtex.to(ctx.dtypes[2]) if gtex is not None else None), None, None, None
 
 
 class _ChamferFn(torch.autograd.Function):
