@@ -12,6 +12,7 @@ For every (batch, mode) prints microseconds per call for
 import argparse
 import os
 import sys
+import gc
 import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -67,14 +68,23 @@ def main():
                 (out * w).sum().backward()
 
             def timeit(fn):
-                for _ in range(5):
+                for _ in range(25):                 # the allocator settles on the new sizes meanwhile
                     fn()
                 torch.cuda.synchronize()
+                gc.collect()
+                gc.disable()                        # no collector pause inside the timed loop
                 t0 = time.perf_counter()
+                worst = 0.0
                 for _ in range(args.iters):
+                    t1 = time.perf_counter()
                     fn()
+                    worst = max(worst, time.perf_counter() - t1)
                 torch.cuda.synchronize()
-                return (time.perf_counter() - t0) / args.iters * 1e6
+                total = time.perf_counter() - t0
+                gc.enable()
+                if worst > 0.2 * total and args.iters >= 10:
+                    print("  (one call took %.0f us of the loop's %.0f us on the host)" % (worst * 1e6, total * 1e6))
+                return total / args.iters * 1e6
 
             if args.profile:
                 import cProfile
@@ -104,6 +114,10 @@ def main():
             print("B %3d %-8s staged %8.1f us  fused %8.1f us  graph %8.1f us   (%.0f / %.0f / %.0f img/s)"
                   % (B, mode, t_staged, t_fused, t_graph, B / t_staged * 1e6, B / t_fused * 1e6,
                      B / t_graph * 1e6), flush=True)
+            # the graph's private memory pool would otherwise stay with the allocator and disturb
+            # the eager timings of the configurations that follow
+            del graph
+            torch.cuda.empty_cache()
 
 
 if __name__ == "__main__":
