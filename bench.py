@@ -18,6 +18,7 @@ formulas (oracle port) on the host cores, on a bounded sample.
 """
 import argparse
 import ctypes
+import gc
 import json
 import os
 import sys
@@ -203,18 +204,21 @@ def main():
     slot = {i: j for j, i in enumerate(timed_steps)}
     pp = ctypes.byref(p)
 
+    # the buffers are the same on every step: their pointer arguments are built once
+    a_fv, a_tex, a_rgba, a_rec, a_saved = vp(fv), vp(tex), vp(rgba), vp(rec), vp(saved)
+    a_grad, a_gfv, a_gtex, a_ws, a_wsb = vp(grad), vp(gfv), vp(gtex), vp(ws), ctypes.c_size_t(ws_b)
+
     def step(i=None):
         j = slot.get(i)
         if j is None:
-            L.check(lib.sv3d_raster_forward(pp, vp(fv), vp(tex), vp(rgba), vp(rec), vp(saved), stream), "fwd")
-            L.check(lib.sv3d_raster_backward(pp, vp(tex), vp(rec), vp(saved), vp(grad), vp(gfv), vp(gtex),
-                                             vp(ws), ctypes.c_size_t(ws_b), stream), "bwd")
+            L.check(lib.sv3d_raster_forward(pp, a_fv, a_tex, a_rgba, a_rec, a_saved, stream), "fwd")
+            L.check(lib.sv3d_raster_backward(pp, a_tex, a_rec, a_saved, a_grad, a_gfv, a_gtex, a_ws, a_wsb,
+                                             stream), "bwd")
         else:
-            L.check(lib.sv3d_raster_forward_timed(pp, vp(fv), vp(tex), vp(rgba), vp(rec), vp(saved), stream,
+            L.check(lib.sv3d_raster_forward_timed(pp, a_fv, a_tex, a_rgba, a_rec, a_saved, stream,
                                                   fe[2 * j], fe[2 * j + 1]), "fwd")
-            L.check(lib.sv3d_raster_backward_timed(pp, vp(tex), vp(rec), vp(saved), vp(grad), vp(gfv),
-                                                   vp(gtex), vp(ws), ctypes.c_size_t(ws_b), stream,
-                                                   be[2 * j], be[2 * j + 1]), "bwd")
+            L.check(lib.sv3d_raster_backward_timed(pp, a_tex, a_rec, a_saved, a_grad, a_gfv, a_gtex, a_ws,
+                                                   a_wsb, stream, be[2 * j], be[2 * j + 1]), "bwd")
 
     def barrier():
         if world > 1:
@@ -223,6 +227,10 @@ def main():
 
     for _ in range(W):
         step()
+    # no pause of Python's cyclic collector inside the timed region: a full collection of the
+    # process's objects takes longer than the GPU's launch queue can cover
+    gc.collect()
+    gc.disable()
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -231,6 +239,7 @@ def main():
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
+    gc.enable()
     if world > 1:
         import torch.distributed as dist
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
