@@ -13,19 +13,18 @@ from sv3d import meshreg
 
 
 def cotangent(V, F):
-    """laplacian.py:106-137.  V: B x N x 3, F: B x F x 3 -> B x F x 3, per face and for its edges
-    23, 31, 12: (sum of the other two squared edge lengths - its own) / (2 * Heron area) / 4."""
-    idx = F.long()[..., None].expand(-1, -1, -1, 3)
-    v1 = torch.gather(V, 1, idx[:, :, 0])
-    v2 = torch.gather(V, 1, idx[:, :, 1])
-    v3 = torch.gather(V, 1, idx[:, :, 2])
-    l1 = (v2 - v3).pow(2).sum(2).sqrt()
-    l2 = (v3 - v1).pow(2).sum(2).sqrt()
-    l3 = (v1 - v2).pow(2).sum(2).sqrt()
-    sp = (l1 + l2 + l3) * 0.5
-    A = 2 * torch.sqrt(sp * (sp - l1) * (sp - l2) * (sp - l3))
-    C = torch.stack([l2 ** 2 + l3 ** 2 - l1 ** 2, l1 ** 2 + l3 ** 2 - l2 ** 2, l1 ** 2 + l2 ** 2 - l3 ** 2], 2)
-    return C / A.unsqueeze(2) / 4
+    """laplacian.py:106-137.  V: B x N x 3, F: B x F x 3 -> B x F x 3: per face, for the edges
+    opposite its corners 1, 2, 3 (the reference's columns 23, 31, 12), the sum of the other two
+    squared edge lengths minus its own, over 2 * (Heron area) * 4 -- half the cotangent of the angle
+    opposite that edge."""
+    batch = torch.arange(V.shape[0], device=V.device)[:, None]
+    corners = [V[batch, F[:, :, k].long()] for k in range(3)]                       # three B x F x 3
+    # edge k is opposite corner k
+    length = torch.stack([(corners[(k + 1) % 3] - corners[(k + 2) % 3]).pow(2).sum(-1).sqrt() for k in range(3)], -1)
+    half = length.sum(-1) * 0.5
+    heron = half * (half - length[..., 0]) * (half - length[..., 1]) * (half - length[..., 2])
+    sq = length.pow(2)
+    return (sq.sum(-1, keepdim=True) - 2 * sq) / (2 * heron.sqrt())[..., None] / 4
 
 
 class LaplacianModule(torch.nn.Module):
