@@ -264,6 +264,19 @@ int sv3d_distance_transform_workspace(int32_t B, int32_t H, int32_t W, size_t *b
 int sv3d_distance_transform(const float *masks, int32_t B, int32_t H, int32_t W, int32_t barrier,
                             float k, float *out, void *workspace, size_t workspace_bytes, void *stream);
 
+/* sv3d_distance_transform for callers that cannot allocate device memory: code under HIP graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc.  It has no counterpart in the
+ * reference.  Same arguments, launches and results as sv3d_distance_transform without the
+ * workspace pair: the per-row distances live in an array of SV3D_DT_STATIC_MAX_PIXELS words
+ * (16 MiB) inside the library's device image, one copy per GPU, held until the process ends.
+ *   B*H*W > SV3D_DT_STATIC_MAX_PIXELS -> SV3D_ERR_WORKSPACE (nothing is launched).
+ *   The call allocates and frees nothing.  Every call on one GPU uses that GPU's array: calls
+ *   whose execution can overlap on one GPU (different streams, no ordering between them) race;
+ *   calls ordered on one stream, or on different GPUs, do not.                                 */
+#define SV3D_DT_STATIC_MAX_PIXELS (4 * 1024 * 1024)   /* e.g. 64 masks of 256 x 256 */
+int sv3d_distance_transform_static(const float *masks, int32_t B, int32_t H, int32_t W,
+                                   int32_t barrier, float k, float *out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

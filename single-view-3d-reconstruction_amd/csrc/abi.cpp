@@ -7,7 +7,7 @@ extern "C" const char *sv3d_strerror(int status)
     case SV3D_OK: return "ok";
     case SV3D_ERR_INVALID_ARG: return "invalid argument (null pointer, non-positive size or bad enum)";
     case SV3D_ERR_UNSUPPORTED: return "size outside the supported range";
-    case SV3D_ERR_WORKSPACE: return "workspace smaller than sv3d_raster_sizes() requires";
+    case SV3D_ERR_WORKSPACE: return "workspace too small for this call (or input beyond the built-in array of a *_static call)";
     case SV3D_ERR_LAUNCH: return "kernel launch failed (hipGetLastError)";
     default: return "unknown sv3d status";
     }

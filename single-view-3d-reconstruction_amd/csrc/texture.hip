@@ -7,6 +7,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <mutex>
+
 #include "sv3d_hip.h"
 
 namespace {
@@ -293,15 +295,12 @@ extern "C" int sv3d_distance_transform_workspace(int32_t B, int32_t H, int32_t W
     return SV3D_OK;
 }
 
-extern "C" int sv3d_distance_transform(const float *masks, int32_t B, int32_t H, int32_t W, int32_t barrier,
-                                       float k, float *out, void *workspace, size_t workspace_bytes,
-                                       void *stream)
+namespace {
+
+// Both launches of the transform; `pairs` holds B*H*W words of device memory.
+int distance_transform_launch(const float *masks, int B, int H, int W, int barrier, float k, float *out,
+                              uint32_t *pairs, hipStream_t s)
 {
-    if (!masks || !out || !workspace || B <= 0 || H <= 0 || W <= 0) return SV3D_ERR_INVALID_ARG;
-    if (W > kDtMaxSize || H > kDtMaxSize || B > 65535) return SV3D_ERR_UNSUPPORTED;
-    if (workspace_bytes < (size_t)B * H * W * sizeof(uint32_t)) return SV3D_ERR_WORKSPACE;
-    hipStream_t s = (hipStream_t)stream;
-    uint32_t *pairs = static_cast<uint32_t *>(workspace);
     const int rows_per_wg = kDtThreads / 64;
     hipLaunchKernelGGL(dt_rows_kernel, dim3((H + rows_per_wg - 1) / rows_per_wg, B), dim3(kDtThreads), 0, s, masks,
                        H, W, pairs);
@@ -319,4 +318,55 @@ extern "C" int sv3d_distance_transform(const float *masks, int32_t B, int32_t H,
     else
         hipLaunchKernelGGL(dt_columns_kernel<false>, grid, dim3(kDtThreads), 0, s, pairs, H, W, k, barrier ? 1 : 0, out);
     return launch_status();
+}
+
+// Row-distance words of the entry point that allocates nothing: one array per GPU the library
+// runs on, held until the process ends.  In host code this name is only a handle for
+// hipGetSymbolAddress; kernels get the per-device address looked up below.
+static __device__ __align__(256) uint32_t scratch[SV3D_DT_STATIC_MAX_PIXELS];
+
+constexpr int kMaxDevices = 64;
+uint32_t *g_scratch_ptr[kMaxDevices];            // device address of `scratch` on each GPU, once looked up
+std::mutex g_scratch_mutex;
+
+// Address of the current device's copy of `scratch`, or nullptr.
+uint32_t *scratch_on_current_device()
+{
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return nullptr;
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[dev]) {
+        void *p = nullptr;
+        if (hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)) != hipSuccess || !p) {
+            (void)hipGetLastError();
+            return nullptr;
+        }
+        g_scratch_ptr[dev] = static_cast<uint32_t *>(p);
+    }
+    return g_scratch_ptr[dev];
+}
+
+}  // namespace
+
+extern "C" int sv3d_distance_transform(const float *masks, int32_t B, int32_t H, int32_t W, int32_t barrier,
+                                       float k, float *out, void *workspace, size_t workspace_bytes,
+                                       void *stream)
+{
+    if (!masks || !out || !workspace || B <= 0 || H <= 0 || W <= 0) return SV3D_ERR_INVALID_ARG;
+    if (W > kDtMaxSize || H > kDtMaxSize || B > 65535) return SV3D_ERR_UNSUPPORTED;
+    if (workspace_bytes < (size_t)B * H * W * sizeof(uint32_t)) return SV3D_ERR_WORKSPACE;
+    return distance_transform_launch(masks, B, H, W, barrier, k, out, static_cast<uint32_t *>(workspace),
+                                     (hipStream_t)stream);
+}
+
+extern "C" int sv3d_distance_transform_static(const float *masks, int32_t B, int32_t H, int32_t W,
+                                              int32_t barrier, float k, float *out, void *stream)
+{
+    if (!masks || !out || B <= 0 || H <= 0 || W <= 0) return SV3D_ERR_INVALID_ARG;
+    if (W > kDtMaxSize || H > kDtMaxSize || B > 65535) return SV3D_ERR_UNSUPPORTED;
+    if ((size_t)B * H * W > (size_t)SV3D_DT_STATIC_MAX_PIXELS) return SV3D_ERR_WORKSPACE;
+    uint32_t *pairs = scratch_on_current_device();
+    if (!pairs) return SV3D_ERR_LAUNCH;
+    // every word the column pass reads was written by the row pass of this same call: nothing to clear
+    return distance_transform_launch(masks, B, H, W, barrier, k, out, pairs, (hipStream_t)stream);
 }

@@ -21,7 +21,7 @@ EXPORTS = (
     "sv3d_face_gather_n", "sv3d_face_scatter_n",
     "sv3d_laplacian_loss", "sv3d_flatten_loss", "sv3d_mesh_spmv",
     "sv3d_texture_sample", "sv3d_texture_sample_backward", "sv3d_distance_transform",
-    "sv3d_distance_transform_workspace",
+    "sv3d_distance_transform_workspace", "sv3d_distance_transform_static",
 )
 
 
@@ -89,6 +89,7 @@ def lib():
         L.sv3d_texture_sample_backward.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, vp, vp]
         L.sv3d_distance_transform.argtypes = [vp, i32, i32, i32, i32, ctypes.c_float, vp, vp, ctypes.c_size_t, vp]
         L.sv3d_distance_transform_workspace.argtypes = [i32, i32, i32, ctypes.POINTER(ctypes.c_size_t)]
+        L.sv3d_distance_transform_static.argtypes = [vp, i32, i32, i32, i32, ctypes.c_float, vp, vp]
         mp = ctypes.POINTER(MeshInput)
         L.sv3d_project_gather.argtypes = [mp, i32, i32, vp, vp]
         L.sv3d_project_scatter.argtypes = [mp, i32, i32, vp, vp, vp, vp]
