@@ -235,7 +235,11 @@ def rasterize_image(fv, tex, S, **kw):
             near_edge = (((fx - fx.round()).abs() < tolf * R) & free[..., 0]) | \
                         (((fy - fy.round()).abs() < tolf * R) & free[..., 1]) | \
                         (((diag - 1).abs() < tolf * R) & free[..., 2])
-            unstable = unstable | (near_edge & contrib & (D.detach() > 1e-7)).any(-1)
+            # a pick only matters through the fragment's share of the pixel's colour: faces hidden
+            # behind nearer ones (share below 1e-7) cannot move the pixel whichever texel they take
+            with torch.no_grad():
+                share = (D * E) / (bgw + (D * E).sum(1))[:, None]
+            unstable = unstable | (near_edge & contrib & (share > 1e-7)).any(-1)
             fidx = torch.arange(F)[None].expand(npx, F)
             col = tex[fidx, tid]                                # [P,F,3]
         else:

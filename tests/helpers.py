@@ -47,3 +47,16 @@ def rel_err(a, b):
     a = a.double()
     b = b.double()
     return float((a - b).abs().max() / b.abs().max().clamp(min=1e-30))
+
+
+def elementwise_rel_err(a, b, floor=1e-3, q=0.999):
+    """q-quantile of |a-b| / |b| over the entries of b above `floor` times its largest one: the
+    element-wise companion of `rel_err`, which small entries cannot hide in."""
+    a = a.double().reshape(-1)
+    b = b.double().reshape(-1)
+    big = b.abs() > floor * b.abs().max()
+    if not bool(big.any()):
+        return 0.0
+    r = ((a - b).abs() / b.abs())[big]
+    k = min(r.numel() - 1, int(q * r.numel()))
+    return float(torch.sort(r).values[k])

@@ -1,0 +1,197 @@
+"""The rasterizer at the sizes the training configurations run it at, against the fp64 oracle on
+sampled pixels (the dense oracle cannot hold 512^2 x 1280..5120 pairs at once).
+
+Per image a set of OUTPUT pixels is drawn, half uniformly and half from the object's own pixels
+(alpha > 0 in the kernels' image, which only decides where to look).  The oracle evaluates the
+raster pixels under them (four per output pixel with anti-aliasing) and averages; the incoming
+gradient is non-zero on exactly those output pixels, so the oracle's face and texture gradients
+are the complete ones.  Bars as everywhere: image and gradients 1e-5 of the largest reference
+value.  In addition the element-wise relative error over entries above 1e-3 of the largest one is
+recorded (`p999_*`: its 99.9th percentile) and asserted below 1e-3.  An absolute error of 1e-6 of
+the largest entry -- a tenth of the bar above -- already is 1e-3 of an entry a thousand times
+smaller, so this figure is bounded by (max-norm error) / 1e-3 and says that no class of small
+entries is systematically wrong; measured 5e-5 .. 3.5e-4.  For scale, `fp32_upstream_*` records the
+same figures for the oracle's own upstream-style formulas evaluated densely in fp32 on the same
+inputs (what single precision costs with SoftRas's barycentric `t - w` algebra, before any kernel
+is involved): max-norm 4e-2 .. 6e-2, p999 of order 1.
+
+Sizes follow the reference's defaults (softras.py:33-37: sigma 1e-5, gamma 1e-4, anti-aliasing;
+mesh_net.py:34 tex_size 6; utils/mesh.py:13-14 subdivide 3 / 4; main.py:56 part maps).
+"""
+import json
+import os
+
+import pytest
+import torch
+
+from helpers import camera_space_faces, elementwise_rel_err, load_mesh, rel_err
+from oracle import raster_oracle
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5
+P999_TOL = 1e-3
+_LOG = []
+
+
+def _record(name, **kw):
+    _LOG.append(dict(test=name, **{k: float(v) for k, v in kw.items()}))
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(out):
+        with open(os.path.join(out, "raster_parity_fullsize.json"), "w") as fh:
+            json.dump(_LOG, fh, indent=1)
+
+
+def _textures(mode, B, F, R, seed=2):
+    g = torch.Generator().manual_seed(seed)
+    if mode == "surface":
+        return torch.rand(B, F, R * R, 3, generator=g)
+    if mode == "vertex":
+        return torch.rand(B, F, 3, 3, generator=g)
+    if mode == "vertex8":
+        return torch.rand(B, F, 3, 8, generator=g)
+    return None
+
+
+def _render(fv, tex, img, aa, mode, **kw):
+    import sv3d
+    return sv3d.soft_rasterize(fv, tex, img, anti_aliasing=aa, texture_type=mode if mode != "none" else "surface",
+                               sigma_val=kw.get("sigma", 1e-5), gamma_val=kw.get("gamma", 1e-4),
+                               dist_eps=kw.get("dist_eps", 1e-10),
+                               background_color=kw.get("background", (0., 0., 0.)))
+
+
+def _sample_output_pixels(alpha, n, gen):
+    """n flat output-pixel indices: half uniform, half from the object's pixels."""
+    hw = alpha.numel()
+    uniform = torch.randperm(hw, generator=gen)[: n // 2]
+    obj = torch.nonzero(alpha.reshape(-1) > 0)[:, 0]
+    obj = obj[torch.randperm(obj.numel(), generator=gen)[: n - n // 2]]
+    return torch.unique(torch.cat([uniform, obj]))
+
+
+def _raster_pixels(out_pix, img, aa):
+    """Raster-pixel indices under each output pixel: [n, aa*aa] (row-major in the S x S raster)."""
+    k = 2 if aa else 1
+    S = img * k
+    r, c = out_pix // img, out_pix % img
+    sub = [(k * r + i) * S + (k * c + j) for i in range(k) for j in range(k)]
+    return torch.stack(sub, 1)
+
+
+def sampled_compare(name, fv, tex, img, aa, mode, n_out, check_images=None, fp32_floor=False, **kw):
+    """GPU forward + backward over the whole batch; oracle on `n_out` output pixels of every image
+    in `check_images` (default: all).  Returns the worst errors."""
+    B, F = fv.shape[:2]
+    S = img * (2 if aa else 1)
+    channels = 9 if mode == "vertex8" else 4
+    check = list(range(B)) if check_images is None else list(check_images)
+    gen = torch.Generator().manual_seed(11)
+    x = fv.cuda().requires_grad_(True)
+    t = tex.cuda().requires_grad_(True) if tex is not None else None
+    with torch.no_grad():
+        alpha0 = _render(x, t, img, aa, mode, **kw)[:, -1].cpu()
+
+    # oracle forward on the sampled pixels first: it also says which pixels to leave out
+    per_image = {}
+    for b in check:
+        out_pix = _sample_output_pixels(alpha0[b], n_out, gen)
+        rp = _raster_pixels(out_pix, img, aa)
+        xb = fv[b].double().requires_grad_(True)
+        tb = tex[b].double().requires_grad_(True) if tex is not None else None
+        o = raster_oracle.rasterize_image(xb, tb, S, texture_mode=mode, pixels=rp.reshape(-1), **kw)
+        want = o["rgba"].reshape(channels, -1, rp.shape[1]).mean(-1)              # [C, n]
+        unstable = o["unstable"].reshape(-1, rp.shape[1]).any(-1)                 # [n]
+        vals = (2 * torch.rand(channels, out_pix.numel(), generator=gen) - 1) * (~unstable)[None]
+        per_image[b] = (out_pix, xb, tb, want, unstable, vals)
+
+    # images the oracle does not look at still get a gradient, so the launch does its full work
+    grad = 2 * torch.rand(B, channels, img * img, generator=gen) - 1
+    grad[check] = 0
+    for b, (out_pix, _, _, _, _, vals) in per_image.items():
+        grad[b][:, out_pix] = vals
+    got = _render(x, t, img, aa, mode, **kw)
+    (got * grad.reshape(B, channels, img, img).cuda()).sum().backward()
+    got = got.detach().cpu().reshape(B, channels, -1)
+    gfv = x.grad.cpu()
+    gtex = t.grad.cpu() if t is not None else None
+    assert torch.isfinite(got).all() and torch.isfinite(gfv).all()
+
+    worst = dict(img=0.0, grad_fv=0.0, grad_tex=0.0, p999_fv=0.0, p999_tex=0.0, unstable=0.0)
+    for b, (out_pix, xb, tb, want, unstable, vals) in per_image.items():
+        (want * vals.double()).sum().backward()
+        keep = ~unstable
+        e_img = float((got[b][:, out_pix].double() - want.detach())[:, keep].abs().max() / want.detach().abs().max())
+        worst["img"] = max(worst["img"], e_img)
+        worst["grad_fv"] = max(worst["grad_fv"], rel_err(gfv[b], xb.grad))
+        worst["p999_fv"] = max(worst["p999_fv"], elementwise_rel_err(gfv[b], xb.grad))
+        worst["unstable"] = max(worst["unstable"], float(unstable.float().mean()))
+        assert float(xb.grad.abs().max()) > 0
+        if tb is not None:
+            worst["grad_tex"] = max(worst["grad_tex"], rel_err(gtex[b], tb.grad))
+            worst["p999_tex"] = max(worst["p999_tex"], elementwise_rel_err(gtex[b], tb.grad))
+    if fp32_floor:
+        b = check[0]
+        out_pix, xb, tb, want, unstable, vals = per_image[b]
+        x32 = fv[b].float().requires_grad_(True)
+        t32 = tex[b].float().requires_grad_(True) if tex is not None else None
+        o = raster_oracle.rasterize_image(x32, t32, S, texture_mode=mode,
+                                          pixels=_raster_pixels(out_pix, img, aa).reshape(-1), **kw)
+        (o["rgba"].reshape(channels, -1, 4 if aa else 1).mean(-1) * vals).sum().backward()
+        worst["fp32_upstream_grad_fv"] = rel_err(x32.grad, xb.grad)
+        worst["fp32_upstream_p999_fv"] = elementwise_rel_err(x32.grad, xb.grad)
+    _record(name, **worst)
+    assert worst["unstable"] < 2e-2, worst
+    assert worst["img"] < TOL and worst["grad_fv"] < TOL and worst["grad_tex"] < TOL, worst
+    assert worst["p999_fv"] < P999_TOL and worst["p999_tex"] < P999_TOL, worst
+    return worst
+
+
+def test_surface_rgb_at_the_reference_raster():
+    """The training step's RGB render (main.py:418): 8 images, 512^2 raster pooled to 256^2,
+    1280 faces, 36 texels per face, sigma 1e-5, gamma 1e-4."""
+    verts, faces = load_mesh(3)
+    B = 8
+    fv = camera_space_faces(verts, faces, B, seed=0)
+    tex = _textures("surface", B, faces.shape[0], 6)
+    sampled_compare("c3_surface_512aa_T6", fv, tex, 256, True, "surface", 192, background=(0.2, 0.4, 0.6))
+
+
+def test_mask_at_the_reference_raster():
+    """The step's silhouette render (main.py:417) at the same size."""
+    verts, faces = load_mesh(3)
+    fv = camera_space_faces(verts, faces, 4, seed=2)
+    w = sampled_compare("c3_mask_512aa", fv, None, 256, True, "none", 256, fp32_floor=True)
+    assert w["grad_fv"] < w["fp32_upstream_grad_fv"] and w["p999_fv"] < w["fp32_upstream_p999_fv"]
+
+
+@pytest.mark.parametrize("mode", ["none", "surface"])
+def test_hd_mesh_at_the_reference_raster(mode):
+    """Subdivide 4 (2562 v / 5120 f), 512^2 raster, tex_size 6: the coarse-bin path at size."""
+    verts, faces = load_mesh(4)
+    B = 2
+    fv = camera_space_faces(verts, faces, B, seed=4)
+    tex = _textures(mode, B, faces.shape[0], 6)
+    sampled_compare("c4_hd_%s_512aa_T6" % mode, fv, tex, 256, True, mode, 160, fp32_floor=(mode == "none"))
+
+
+def test_eight_part_maps_at_the_reference_raster():
+    """The part-map pass (main.py:422-426 rendered as eight channels at once), 512^2 raster."""
+    verts, faces = load_mesh(3)
+    B = 2
+    fv = camera_space_faces(verts, faces, B, seed=6)
+    tex = torch.softmax(torch.randn(B, faces.shape[0], 3, 8, generator=torch.Generator().manual_seed(3)), -1)
+    sampled_compare("c5_vertex8_512aa", fv, tex, 256, True, "vertex8", 192)
+
+
+@pytest.mark.parametrize("mode", ["none", "surface"])
+def test_batch_40_launch_against_the_oracle(mode):
+    """40 images x 1280 faces in one launch: the backward's XCD-permuted face order (batch >= 32)
+    and its one-wave-per-face kernels (more than 16384 faces), checked against the oracle on five
+    of the images rather than against smaller launches of the same kernels."""
+    verts, faces = load_mesh(3)
+    B = 40
+    fv = camera_space_faces(verts, faces, B, seed=8)
+    tex = _textures(mode, B, faces.shape[0], 3)
+    sampled_compare("b40_%s_128" % mode, fv, tex, 128, False, mode, 384, check_images=(0, 7, 19, 32, 39),
+                    sigma=1e-4, gamma=1e-3)
