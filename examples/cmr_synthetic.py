@@ -107,6 +107,19 @@ class MeshNetLite(nn.Module):
         return self.mean_v[None] + delta_v, cams, self.cam_prob(z), flow
 
 
+class PartBasisGenerator(nn.Module):
+    """Per-vertex part logits with their own optimizer (mesh_net.py:603-616 in role).  The
+    parameter is only ever reached through `forward`, so that a DistributedDataParallel wrapper
+    sees the use and all-reduces its gradient."""
+
+    def __init__(self, num_vertices, num_parts):
+        super().__init__()
+        self.w = nn.Parameter(torch.randn(num_vertices, num_parts) / num_parts ** 0.5)
+
+    def forward(self, x=None):
+        return F.softmax(self.w, dim=1)                                  # V x Np part probabilities
+
+
 class SyntheticCUB(torch.utils.data.Dataset):
     def __init__(self, n, img_size, seed):
         self.n, self.img_size, self.seed = n, img_size, seed
@@ -136,7 +149,7 @@ class ShapeTrainer(train_utils.Trainer):
         self.model = MeshNetLite(verts, faces.long(), o.num_hypo_cams, o.tex_size)
         if o.channels_last:
             self.model = self.model.to(memory_format=torch.channels_last)
-        self.part_basis_generator = nn.Linear(o.num_parts, verts.shape[0], bias=False)   # vertex part logits
+        self.part_basis_generator = PartBasisGenerator(verts.shape[0], o.num_parts)
         self.renderer = SoftNeuralRenderer(o.img_size)
         self.tex_renderer = SoftNeuralRenderer(o.img_size)
         self.tex_renderer.ambient_light_only()
@@ -180,8 +193,8 @@ class ShapeTrainer(train_utils.Trainer):
         loss = (per_cam * cam_probs).sum(0).mean()
         loss = loss + 0.05 * F.cross_entropy(cam_logits, per_cam.detach().argmin(0))
         if o.seg_train and Np > 0:
-            w = train_utils.unwrap(self.part_basis_generator).weight        # V x Np
-            seg_map = F.softmax(w, dim=1)[None].expand(B2, -1, -1)
+            # through the (possibly DDP-wrapped) module's forward, never its bare parameter
+            seg_map = self.part_basis_generator()[None].expand(B2, -1, -1)
             if o.share_renders:
                 seg = self.vertex_seg_renderer.render_parts(vs, fs, proj_cam, torch.cat([seg_map] * Nc))
             else:

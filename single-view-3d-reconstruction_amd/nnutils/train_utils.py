@@ -215,10 +215,21 @@ class Trainer(object):
         t /= self.env.world_size
         return {k: float(v) for k, v in zip(keys, t.tolist())}
 
+    def skip_step(self):
+        """The reference skips a step whose `set_input` set `self.invalid_batch`
+        (train_utils.py:67,188).  With one process per GPU that decision must be the same on
+        every rank -- a rank that skipped alone would leave the others waiting in the gradient
+        all-reduce -- so the flag is combined over ranks: all skip if any rank's batch is invalid."""
+        if not self.env.distributed:
+            return bool(self.invalid_batch)
+        flag = torch.tensor([1.0 if self.invalid_batch else 0.0], device=self.device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        return bool(flag.item() > 0)
+
     def train_step(self, batch, total_steps, scaler):
         opts = self.opts
         self.set_input(batch)
-        if self.invalid_batch:
+        if self.skip_step():
             return False
         self.optimizer.zero_grad(set_to_none=True)
         if self._second_optimizer():

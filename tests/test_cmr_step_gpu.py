@@ -22,13 +22,13 @@ def test_training_steps_run_and_learn(tmp_path):
     t = cmr_synthetic.ShapeTrainer(o)
     t.init_training()
     before = {k: v.detach().clone() for k, v in t.model.state_dict().items() if v.dtype.is_floating_point}
-    w2 = t.part_basis_generator.weight.detach().clone()
+    w2 = t.part_basis_generator.w.detach().clone()
     assert t.train() == 6
     assert torch.isfinite(t.total_loss)
     after = t.model.state_dict()
     moved = [k for k in before if not torch.equal(before[k], after[k])]
     assert any(k.startswith("shape") for k in moved) and any(k.startswith("cam.") for k in moved)
     assert any(k.startswith("tex") for k in moved) and any(k.startswith("encoder") for k in moved)
-    assert not torch.equal(w2, t.part_basis_generator.weight)           # second optimizer stepped
+    assert not torch.equal(w2, t.part_basis_generator.w)           # second optimizer stepped
     # render batch shape of the reference recipe: Nc * 2B images per render call
     assert t.imgs.shape[0] == 2

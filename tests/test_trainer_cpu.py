@@ -45,28 +45,42 @@ def _make_trainer(opts, env, n=16):
         def define_model(self):
             torch.manual_seed(7)                     # identical initial weights on every rank
             self.model = torch.nn.Sequential(torch.nn.Linear(6, 8), torch.nn.Tanh(), torch.nn.Linear(8, 1))
-            self.part_basis_generator = torch.nn.Linear(1, 1, bias=False)
+            self.part_basis_generator = _Basis()
 
         def define_criterion(self):
             self.crit = torch.nn.MSELoss()
 
+        def forward(self, total_steps=0):
+            # the basis has no input (mesh_net.py:612 `forward(self, x=None)`): it is reached through
+            # the wrapper's call, as the step harness reaches it -- reading `.module.w` instead would
+            # leave its gradient out of the all-reduce and the ranks' copies would drift apart
+            self.total_loss = self.crit(self.part_basis_generator() * self.model(self.x), self.y)
+
         def set_input(self, batch):
             self.x, self.y = (t.to(self.device) for t in batch)
-
-        def forward(self, total_steps=0):
-            self.total_loss = self.crit(self.part_basis_generator(self.model(self.x)), self.y)
+            self.seen_batches = getattr(self, "seen_batches", 0) + 1
+            self.invalid_batch = self.seen_batches in getattr(self.opts, "invalid_on", {}).get(self.env.rank, ())
 
     return Toy(opts, env)
 
 
-def _worker(rank, world, port, tmp, out):
+class _Basis(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.w = torch.nn.Parameter(torch.ones(1))
+
+    def forward(self, x=None):
+        return torch.relu(self.w)
+
+
+def _worker(rank, world, port, tmp, out, invalid_on=None):
     sys.path[:0] = [ROOT, PKG]
     os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     from nnutils import train_utils
     env = train_utils.init_distributed(backend="gloo")
     assert env.world_size == world and env.rank == rank and env.device.type == "cpu"
-    t = _make_trainer(_opts(tmp, seg_train=1, batch_size=4), env)
+    t = _make_trainer(_opts(tmp, seg_train=1, batch_size=4, invalid_on=invalid_on or {}), env)
     t.init_training()
     assert isinstance(t.model, torch.nn.parallel.DistributedDataParallel)
     assert isinstance(t.part_basis_generator, torch.nn.parallel.DistributedDataParallel)
@@ -74,7 +88,7 @@ def _worker(rank, world, port, tmp, out):
     sc = t.reduce_scalars({"rank": float(rank)})
     state = {k: v.clone() for k, v in train_utils.unwrap(t.model).state_dict().items()}
     torch.save({"state": state, "steps": steps, "mean_rank": sc["rank"], "seen": t.images_seen,
-                "w2": train_utils.unwrap(t.part_basis_generator).weight.detach().clone()},
+                "w2": train_utils.unwrap(t.part_basis_generator).w.detach().clone()},
                os.path.join(out, "rank%d.pt" % rank))
     torch.distributed.destroy_process_group()
 
@@ -113,6 +127,20 @@ def test_two_rank_gloo_matches_single_process(tmp_path):
         assert torch.allclose(v, r0["state"][k], rtol=1e-5, atol=1e-6), k
 
 
+def test_invalid_batch_on_one_rank_skips_the_step_on_all(tmp_path):
+    """Only rank 1 flags its second batch invalid: both ranks must skip that step (a rank skipping
+    alone would leave the other in the gradient all-reduce for ever) and stay in lockstep."""
+    tmp = str(tmp_path)
+    mp.spawn(_worker, args=(2, _free_port(), tmp, tmp, {1: (2,)}), nprocs=2, join=True)
+    r0 = torch.load(os.path.join(tmp, "rank0.pt"), weights_only=True)
+    r1 = torch.load(os.path.join(tmp, "rank1.pt"), weights_only=True)
+    for k in r0["state"]:
+        assert torch.equal(r0["state"][k], r1["state"][k]), k
+    assert torch.equal(r0["w2"], r1["w2"])
+    assert r0["steps"] == r1["steps"] == 4
+    assert r0["seen"] == r1["seen"] == 3 * 4 * 2                       # one of the four steps skipped by both
+
+
 def test_single_process_loop_semantics(tmp_path):
     from nnutils import train_utils
     o = _opts(str(tmp_path), num_epochs=3, epoch_fraction=0.1, num_iter=0, save_epoch_freq=2)
@@ -127,7 +155,7 @@ def test_single_process_loop_semantics(tmp_path):
     t2.init_training()
     assert t2.train() == 5
     t2.load_network(t2.model, "pred", "latest")                   # round trip through the snapshot
-    t2.invalid_batch = True
+    o.invalid_on = {0: (t2.seen_batches + 1,)}                    # set_input flags the next batch invalid
     before = [p.clone() for p in t2.model.parameters()]
     t2.train_step(next(iter(t2.dataloader)), 0, torch.amp.GradScaler("cpu", enabled=False))
     assert all(torch.equal(a, b) for a, b in zip(before, t2.model.parameters()))
