@@ -217,8 +217,9 @@ int sv3d_render_forward(const sv3d_raster_params *p, const sv3d_mesh_input *mesh
 int sv3d_laplacian_loss(const float *vertices, const int32_t *row_start, const int32_t *nbr, int32_t B,
                         int32_t V, float *loss, float *grad_vertices, void *stream);
 
-/* `sr.FlattenLoss(faces)(x)` (main.py:203,516): over the E interior edges, quads[e] =
- * (v0, v1, v2, v3) with (v0,v1) the edge and v2, v3 the opposite vertices of its two faces,
+/* `sr.FlattenLoss(faces)(x)` (main.py:203,516): over E edges, quads[e] = (v0, v1, v2, v3) with
+ * (v0,v1) the edge and v2, v3 the opposite vertices of its two faces (which edges of a mesh are
+ * listed is the caller's choice; upstream lists those found at corner positions (0,1), (1,2)),
  *   loss[b] = sum_e (cos_e + 1)^2,  cos_e between the two in-face altitudes onto the edge,
  * with the eps placement of the upstream module (eps = 1e-6 there).  inc[inc_start[v] ..
  * inc_start[v+1]) lists, ascending, the entries 4 e + k for which quads[e][k] == v; it is only

@@ -40,19 +40,25 @@ def laplacian_loss(vertices, faces):
 
 
 def flatten_quads(faces):
-    """Interior edges as (v0, v1, v2, v3): edge (v0 < v1) and the opposite vertex of each of its
-    two faces, edges in ascending (v0, v1) order."""
-    opposite = {}
-    for tri in np.asarray(faces, np.int64):
-        for k in range(3):
-            a, b, c = int(tri[k]), int(tri[(k + 1) % 3]), int(tri[(k + 2) % 3])
-            opposite.setdefault((min(a, b), max(a, b)), []).append(c)
-    quads = [(e[0], e[1], o[0], o[1]) for e, o in sorted(opposite.items()) if len(o) == 2]
+    """The upstream module's edge table, built its way: the set of sorted vertex pairs taken from
+    the face columns 0:2 and 1:3 only (`np.concatenate((faces[:, 0:2], faces[:, 1:3]))`, so an
+    edge lying at corner positions (2,0) in both of its faces never enters); for each pair, going
+    through the faces in order, the remaining vertex of the first face holding both ends is v2 and
+    that of the second face is v3.  Returned in ascending (v0, v1) order (upstream iterates a
+    python set; the loss is a sum, so the order is immaterial).  Pairs held by fewer than two
+    faces are dropped (upstream's v2 / v3 lists would fall out of step on such a mesh)."""
+    f = np.asarray(faces, np.int64)
+    pairs = sorted(set(tuple(sorted(p)) for p in np.concatenate((f[:, 0:2], f[:, 1:3]), 0).tolist()))
+    quads = []
+    for v0, v1 in pairs:
+        rest = [int([v for v in tri if v != v0 and v != v1][0]) for tri in f.tolist() if v0 in tri and v1 in tri]
+        if len(rest) >= 2:
+            quads.append((v0, v1, rest[0], rest[1]))
     return np.asarray(quads, np.int64).reshape(-1, 4)
 
 
 def flatten_loss(vertices, faces, eps=1e-6):
-    """vertices: torch [B,V,3] -> loss [B] = sum over interior edges of (cos + 1)^2, cos between
+    """vertices: torch [B,V,3] -> loss [B] = sum over the edges of `flatten_quads` of (cos + 1)^2, cos between
     the in-face altitudes onto the shared edge, eps placed as in the upstream module."""
     q = torch.from_numpy(flatten_quads(faces))
     v0, v1 = vertices[:, q[:, 0]], vertices[:, q[:, 1]]

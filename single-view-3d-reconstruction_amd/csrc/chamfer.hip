@@ -283,7 +283,8 @@ __global__ __launch_bounds__(sv3d_dev::kSortThreads) void chamfer_grad_sorted_ke
     }
 }
 
-constexpr size_t kSortLdsDefault = 64 * 1024;
+constexpr size_t kSortLdsDefault = 48 * 1024;    // above this the launch raises the kernel's dynamic-LDS limit (static
+                                                 // arrays count against the same 64 KiB default)
 constexpr size_t kSortLdsMax = 150 * 1024;
 
 inline int launch_status()

@@ -60,7 +60,7 @@ __global__ __launch_bounds__(kThreads) void face_scatter_kernel(
         __syncthreads();
         int *flat = reinterpret_cast<int *>(s_slots);
         for (int i = threadIdx.x; i < kScanTile; i += kThreads)
-            flat[i] = i < tn ? fb[t0 + i] : -1;
+            flat[i] = i < tn ? min(max(fb[t0 + i], 0), V - 1) : -1;      // clamped like the gather's reads
         __syncthreads();
         const int n4 = (tn + 3) / 4;
         for (int i = 0; i < n4; ++i) {
@@ -227,7 +227,8 @@ __global__ __launch_bounds__(kSortThreads) void camera_backward_kernel(
     block_sum7(acc, s_red, grad_cams + (long)b * 7);
 }
 
-constexpr size_t kSortLdsDefault = 64 * 1024;    // dynamic LDS a launch may ask for unprompted
+constexpr size_t kSortLdsDefault = 48 * 1024;    // dynamic LDS a launch asks for unprompted; the kernels' static
+                                                 // arrays (under 1 KiB) count against the same 64 KiB default
 constexpr size_t kSortLdsMax = 150 * 1024;       // of the CU's 160 KiB, less the static arrays
 
 inline size_t sort_lds_bytes(int V, int F) { return ((size_t)2 * V + (size_t)3 * F) * sizeof(int); }

@@ -14,7 +14,7 @@ namespace {
 
 constexpr int kRegThreads = 1024;
 constexpr int kSpmvThreads = 256;
-constexpr size_t kLdsDefault = 64 * 1024;
+constexpr size_t kLdsDefault = 48 * 1024;     // static arrays count against the same 64 KiB default
 constexpr size_t kLdsMax = 150 * 1024;
 
 __device__ inline int clampi(int v, int n) { return min(max(v, 0), n - 1); }

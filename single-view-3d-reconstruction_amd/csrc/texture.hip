@@ -307,7 +307,7 @@ int distance_transform_launch(const float *masks, int B, int H, int W, int barri
     const dim3 grid((W + kDtStrip - 1) / kDtStrip, (H + kDtRowsPerGroup - 1) / kDtRowsPerGroup, B);
     const size_t lds = (size_t)H * kDtStrip * sizeof(uint32_t);
     bool staged = H <= kDtLdsRows;
-    if (staged && lds > 64 * 1024 &&
+    if (staged && lds > 48 * 1024 &&
         hipFuncSetAttribute(reinterpret_cast<const void *>(&dt_columns_kernel<true>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
         (void)hipGetLastError();

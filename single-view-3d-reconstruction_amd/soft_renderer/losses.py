@@ -65,8 +65,9 @@ class LaplacianLoss(nn.Module):
 
 
 class FlattenLoss(nn.Module):
-    """Penalises the dihedral angle across every interior edge: (cos + 1)^2 summed over
-    edges, cos between the two in-face altitudes onto the shared edge."""
+    """Penalises the dihedral angle across the edges of `meshreg.edge_quads` (the upstream
+    module's list: edges found at corner positions (0,1) or (1,2) of some face): (cos + 1)^2
+    summed over them, cos between the two in-face altitudes onto the shared edge."""
 
     def __init__(self, faces, average=False):
         super(FlattenLoss, self).__init__()

@@ -39,8 +39,12 @@ def neighbour_csr(faces, num_vertices):
 
 
 def edge_quads(faces):
-    """[E,4] int64 (v0, v1, v2, v3): the interior edges (v0 < v1), ordered by (v0, v1), with the
-    opposite vertices of their two faces in face order."""
+    """[E,4] int64 (v0, v1, v2, v3), the edge list of the upstream `FlattenLoss` (built from the
+    faces at main.py:203): the distinct sorted pairs (v0 < v1) found at corner positions (0,1) and
+    (1,2) of the faces -- an edge that sits at positions (2,0) in both of its faces is not in the
+    list (about one edge in nine on an icosphere) -- ordered by (v0, v1), with v2 / v3 the
+    opposite vertex of the first / second face, in face order, that holds the edge.  Edges with
+    one face only are left out."""
     f = _faces_np(faces)
     nv = int(f.max()) + 1 if f.size else 0
     a = np.concatenate([f[:, [0, 1, 2]], f[:, [1, 2, 0]], f[:, [2, 0, 1]]])      # edge (a,b), opposite c
@@ -50,8 +54,10 @@ def edge_quads(faces):
     key = (lo * nv + hi)[order]
     opp = a[order, 2]
     uniq, first, count = np.unique(key, return_index=True, return_counts=True)
-    sel = first[count == 2]
-    return np.stack([uniq[count == 2] // nv, uniq[count == 2] % nv, opp[sel], opp[sel + 1]], 1).reshape(-1, 4)
+    listed = np.unique((lo * nv + hi)[: 2 * f.shape[0]])      # positions (0,1) and (1,2) only
+    take = (count == 2) & np.isin(uniq, listed)
+    sel = first[take]
+    return np.stack([uniq[take] // nv, uniq[take] % nv, opp[sel], opp[sel + 1]], 1).reshape(-1, 4)
 
 
 def incidence_csr(quads, num_vertices):

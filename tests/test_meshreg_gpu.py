@@ -35,7 +35,9 @@ def test_host_tables_match_the_oracle_topology():
         assert list(nbr[row_start[v]:row_start[v + 1]]) == list(np.flatnonzero(lap[v] < 0))
     q = meshreg.edge_quads(faces)
     assert np.array_equal(q, mo.flatten_quads(faces.numpy()))
-    assert q.shape == (1920, 4)                            # closed icosphere: E = 3 F / 2
+    # upstream lists only the edges seen at corner positions (0,1) or (1,2) of some face: on this
+    # icosphere 310 of the 3 F / 2 = 1920 edges sit at positions (2,0) in both of their faces
+    assert q.shape == (1610, 4)
     inc_start, inc = meshreg.incidence_csr(q, V)
     assert inc.size == 4 * q.shape[0] and inc_start[-1] == inc.size
     for v in (0, 5, V - 1):
@@ -43,6 +45,33 @@ def test_host_tables_match_the_oracle_topology():
         assert np.all(np.diff(ent) > 0) and np.all(q.reshape(-1)[ent] == v)
     start, col, slot = meshreg.csr_from_coo([2, 0, 2, 0], [1, 3, 1, 0], 3)
     assert list(start) == [0, 2, 2, 3] and list(col) == [0, 3, 1] and list(slot) == [2, 1, 2, 0]
+
+
+TETRAHEDRON = np.array([[0, 1, 2], [0, 3, 1], [1, 3, 2], [2, 3, 0]])
+# by hand: columns 0:2 give (0,1) (0,3) (1,3) (2,3), columns 1:3 give (1,2) (1,3) (2,3) (0,3); edge
+# (0,2) sits at corner positions (2,0) of faces 0 and 3 and is never listed; v2 / v3 = the third
+# vertex of the first / second face, in face order, holding the edge
+TETRAHEDRON_QUADS = [[0, 1, 2, 3], [0, 3, 1, 2], [1, 2, 0, 3], [1, 3, 0, 2], [2, 3, 1, 0]]
+TETRAHEDRON_VERTS = np.array([[1.0, 1, 1], [1, -1, -1], [-1, 1, -1], [-1, -1, 1]])
+
+
+def test_flatten_edge_list_hand_computed_tetrahedron():
+    """Regular tetrahedron: the angle between the two in-face altitudes onto a shared edge is the
+    dihedral angle, cos = 1/3, so every listed edge adds (1/3 + 1)^2 = 16/9: five edges, 80/9."""
+    from sv3d import meshreg
+    assert meshreg.edge_quads(TETRAHEDRON).tolist() == TETRAHEDRON_QUADS
+    assert mo.flatten_quads(TETRAHEDRON).tolist() == TETRAHEDRON_QUADS
+    loss = mo.flatten_loss(torch.from_numpy(TETRAHEDRON_VERTS)[None], TETRAHEDRON, eps=1e-12)
+    assert abs(float(loss) - 80.0 / 9.0) < 1e-9
+
+
+@pytest.mark.gpu
+def test_flatten_loss_tetrahedron_on_the_gpu():
+    import soft_renderer as sr
+    x = torch.from_numpy(TETRAHEDRON_VERTS).float()[None].cuda()
+    got = sr.FlattenLoss(torch.from_numpy(TETRAHEDRON))(x)
+    want = mo.flatten_loss(torch.from_numpy(TETRAHEDRON_VERTS)[None], TETRAHEDRON)
+    assert abs(float(got) - float(want)) < 1e-5 * float(want) and abs(float(got) - 80.0 / 9.0) < 1e-4
 
 
 def test_cotangent_oracle_properties():
