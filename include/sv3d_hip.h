@@ -63,6 +63,10 @@ typedef struct sv3d_raster_params {
     float sigma;           /* sigma_val */
     float dist_eps;        /* dist_eps as passed by the caller (1e-10), NOT its logit          */
     float gamma;           /* gamma_val */
+    int32_t alpha_only;    /* 1 (SV3D_TEX_NONE only): the caller takes the silhouette alone, as     */
+                           /*   `self.renderer(vs, fs)[:, -1]` does at nnutils/softras.py:64:        */
+                           /*   rgba_out and grad_rgba are [B,1,S/aa,S/aa], the alpha plane; the     */
+                           /*   three constant background planes are neither written nor read        */
 } sv3d_raster_params;
 
 const char *sv3d_strerror(int status);

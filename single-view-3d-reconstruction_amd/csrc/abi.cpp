@@ -13,4 +13,4 @@ extern "C" const char *sv3d_strerror(int status)
     }
 }
 
-extern "C" int sv3d_abi_version(void) { return 1; }
+extern "C" int sv3d_abi_version(void) { return 2; }

@@ -76,6 +76,7 @@ struct DevParams {
     float ssum0;                  // exp(eps / gamma): weight of the background term
     float inv_S;                  // 1 / S
     int alpha_fast;               // dist_eps so small that 1 + exp(-threshold/sigma) == 1 in fp32
+    int alpha_only;               // silhouette mode: the image (and its gradient) is the alpha plane alone
 };
 
 // Face record layout (float index):
@@ -83,17 +84,19 @@ struct DevParams {
 //  6..11  e0x e0y e1x e1y e2x e2y        e_k = p_{k+1} - p_k
 // 12..14  1/|e_k|^2 (0 for a zero-length edge)
 // 15      1/det, det = cross(p1-p0, p2-p0) clamped away from 0 by 1e-10
-// 16..19  cull box: xmin-margin, xmax+margin, ymin-margin, ymax+margin
+// 16..19  f0x f0y f1x f1y        f_k = e_k / det: cross(f_k, pixel - p_k) is the barycentric
+//                                coordinate of the vertex opposite to edge k
 // 20..22  1/z_k
 // 23..25  (z_k - z_ref)/z_k
 // 26      flags (bit 0: front facing)
 // 27      z_ref
 // 28..29  pixel box, four int16: col0 col1 | row0 row1   (also kept in a compact array)
+// 30..31  f2x f2y
 struct FaceRec {
     float p0x, p0y, p1x, p1y, p2x, p2y;
     float e0x, e0y, e1x, e1y, e2x, e2y;
     float il0, il1, il2, inv_det;
-    float bx0, bx1, by0, by1;
+    float f0x, f0y, f1x, f1y, f2x, f2y;
     float iz0, iz1, iz2;
     float q0, q1, q2;
     int flags;
@@ -102,13 +105,13 @@ struct FaceRec {
 
 __device__ inline FaceRec load_rec(const float4 *r)
 {
-    const float4 a = r[0], b = r[1], c = r[2], d = r[3], e = r[4], f = r[5], g = r[6];
+    const float4 a = r[0], b = r[1], c = r[2], d = r[3], e = r[4], f = r[5], g = r[6], h = r[7];
     FaceRec o;
     o.p0x = a.x; o.p0y = a.y; o.p1x = a.z; o.p1y = a.w;
     o.p2x = b.x; o.p2y = b.y; o.e0x = b.z; o.e0y = b.w;
     o.e1x = c.x; o.e1y = c.y; o.e2x = c.z; o.e2y = c.w;
     o.il0 = d.x; o.il1 = d.y; o.il2 = d.z; o.inv_det = d.w;
-    o.bx0 = e.x; o.bx1 = e.y; o.by0 = e.z; o.by1 = e.w;
+    o.f0x = e.x; o.f0y = e.y; o.f1x = e.z; o.f1y = e.w; o.f2x = h.z; o.f2y = h.w;
     o.iz0 = f.x; o.iz1 = f.y; o.iz2 = f.z; o.q0 = f.w;
     o.q1 = g.x; o.q2 = g.y; o.flags = __float_as_int(g.z); o.zref = g.w;
     return o;
@@ -170,13 +173,10 @@ __device__ inline PairGeom pair_geom(const FaceRec &r, const Pixel &px, const De
     const float dd0 = d0x * d0x + d0y * d0y;
     const float dd1 = d1x * d1x + d1y * d1y;
     const float dd2 = d2x * d2x + d2y * d2y;
-    // edge functions: cross(e_k, pixel - p_k); w of the vertex opposite to edge k
-    const float c0 = r.e0y * a0x - r.e0x * a0y;
-    const float c1 = r.e1y * a1x - r.e1x * a1y;
-    const float c2 = r.e2y * a2x - r.e2x * a2y;
-    g.w0 = c1 * r.inv_det;
-    g.w1 = c2 * r.inv_det;
-    g.w2 = c0 * r.inv_det;
+    // scaled edge functions cross(e_k, pixel - p_k) / det: w of the vertex opposite to edge k
+    g.w2 = r.f0y * a0x - r.f0x * a0y;
+    g.w0 = r.f1y * a1x - r.f1x * a1y;
+    g.w1 = r.f2y * a2x - r.f2x * a2y;
     g.k0 = (dd0 <= dd1) && (dd0 <= dd2);
     g.k1 = !g.k0 && (dd1 <= dd2);
     g.k2 = !g.k0 && !g.k1;
@@ -184,7 +184,7 @@ __device__ inline PairGeom pair_geom(const FaceRec &r, const Pixel &px, const De
     g.t = g.k0 ? t0 : (g.k1 ? t1 : t2);
     g.dx = g.k0 ? d0x : (g.k1 ? d1x : d2x);
     g.dy = g.k0 ? d0y : (g.k1 ? d1y : d2y);
-    g.inside = (g.w0 > 0.f) & (g.w1 > 0.f) & (g.w2 > 0.f);       // no short circuit: plain mask ands
+    g.inside = fminf(g.w0, fminf(g.w1, g.w2)) > 0.f;              // one v_min3 and one compare
     // A pixel outside the face's cull box (bbox widened by sqrt(threshold)) is farther than
     // sqrt(threshold) from the triangle, so the distance test alone implements both culls.
     g.act = g.inside || g.d2 < P.threshold;
@@ -215,10 +215,10 @@ __device__ inline float pair_one_minus_D(const FaceRec &r, const Pixel &px, cons
     const float d1x = fmaf(t1, r.e1x, a1x), d1y = fmaf(t1, r.e1y, a1y);
     const float d2x = fmaf(t2, r.e2x, a2x), d2y = fmaf(t2, r.e2y, a2y);
     const float d2 = fminf(d0x * d0x + d0y * d0y, fminf(d1x * d1x + d1y * d1y, d2x * d2x + d2y * d2y));
-    const float c0 = r.e0y * a0x - r.e0x * a0y;
-    const float c1 = r.e1y * a1x - r.e1x * a1y;
-    const float c2 = r.e2y * a2x - r.e2x * a2y;
-    const bool inside = (c1 * r.inv_det > 0.f) & (c2 * r.inv_det > 0.f) & (c0 * r.inv_det > 0.f);
+    const float w2 = r.f0y * a0x - r.f0x * a0y;
+    const float w0 = r.f1y * a1x - r.f1x * a1y;
+    const float w1 = r.f2y * a2x - r.f2x * a2y;
+    const bool inside = fminf(w0, fminf(w1, w2)) > 0.f;
     const float e = ex2((inside ? d2 : -d2) * -P.neg_l2e_over_sigma);
     return rcp(1.f + e);
 }
@@ -318,13 +318,14 @@ __device__ inline void setup_face(const DevParams &P, int gid, float x0, float y
     r[0] = make_float4(x0, y0, x1, y1);
     r[1] = make_float4(x2, y2, e0x, e0y);
     r[2] = make_float4(e1x, e1y, e2x, e2y);
+    const float inv_det = 1.f / det;
     r[3] = make_float4(l0 > 0.f ? 1.f / l0 : 0.f, l1 > 0.f ? 1.f / l1 : 0.f,
-                       l2 > 0.f ? 1.f / l2 : 0.f, 1.f / det);
-    r[4] = make_float4(bx0, bx1, by0, by1);
+                       l2 > 0.f ? 1.f / l2 : 0.f, inv_det);
+    r[4] = make_float4(e0x * inv_det, e0y * inv_det, e1x * inv_det, e1y * inv_det);
     r[5] = make_float4(iz0, iz1, iz2, (z0 - zref) * iz0);
     r[6] = make_float4((z1 - zref) * iz1, (z2 - zref) * iz2,
                        __int_as_float(raw_det < 0.f ? 1 : 0), zref);
-    r[7] = make_float4(__uint_as_float(box.x), __uint_as_float(box.y), 0.f, 0.f);
+    r[7] = make_float4(__uint_as_float(box.x), __uint_as_float(box.y), e2x * inv_det, e2y * inv_det);
     pbox[gid] = box;
 }
 
@@ -575,8 +576,10 @@ __attribute__((amdgpu_waves_per_eu(MODE == SV3D_TEX_VERTEX8 ? 7 : 8))) void rast
     const float bcx = 0.5f * (bxa + bxb), bcy = 0.5f * (bya + byb);
     const float bhx = 0.5f * (bxb - bxa), bhy = 0.5f * (byb - bya);
     auto block_may_touch = [&](const float4 *r) -> bool {
-        const float4 bb = r[4];
-        if (bxa > bb.y || bxb < bb.x || bya > bb.w || byb < bb.z) return false;
+        const float4 q7 = r[7];
+        int fc0, fc1, fr0, fr1;                                 // the face's pixel box
+        unpack_box(make_uint2(__float_as_uint(q7.x), __float_as_uint(q7.y)), fc0, fc1, fr0, fr1);
+        if (fc1 < blk_c0 || fc0 > blk_c0 + 7 || fr1 < blk_r0 || fr0 > blk_r0 + 7) return false;
         const float4 q0 = r[0], q1 = r[1], q2 = r[2], q3 = r[3];
         const float sgn = q3.w > 0.f ? 1.f : -1.f;              // orientation (sign of 1/det)
         // edge k: start point, direction, 1/|e|^2
@@ -820,22 +823,28 @@ __attribute__((amdgpu_waves_per_eu(MODE == SV3D_TEX_VERTEX8 ? 7 : 8))) void rast
             sp[2] = make_float4(o[5], o[6], o[7], 0.f);
         }
     }
+    // planes of the image: colours then alpha, or the alpha plane alone
+    const bool only_alpha = MODE == SV3D_TEX_NONE && P.alpha_only;
+    const int planes = only_alpha ? 1 : NC + 1, first = only_alpha ? NC : 0;
     if (P.aa == 2) {
         const int H = S >> 1;
         const size_t plane = (size_t)H * H;
-        const size_t ob = ((size_t)b * (NC + 1) * H + (row >> 1)) * H + (col >> 1);
+        const size_t ob = ((size_t)b * planes * H + (row >> 1)) * H + (col >> 1);
 #pragma unroll
         for (int c = 0; c <= NC; ++c) {
+            if (c < first) continue;
             float v = inimg ? o[c] : 0.f;
             v += __shfl_xor(v, 1);
             v += __shfl_xor(v, 2);
-            if (sub == 0 && inimg) rgba[ob + c * plane] = 0.25f * v;
+            if (sub == 0 && inimg) rgba[ob + (c - first) * plane] = 0.25f * v;
         }
     } else if (inimg) {
-        const size_t ob = ((size_t)b * (NC + 1) * S + row) * S + col;
+        const size_t ob = ((size_t)b * planes * S + row) * S + col;
         const size_t plane = (size_t)S * S;
 #pragma unroll
-        for (int c = 0; c <= NC; ++c) rgba[ob + c * plane] = o[c];
+        for (int c = 0; c <= NC; ++c) {
+            if (c >= first) rgba[ob + (c - first) * plane] = o[c];
+        }
     }
     SV3D_STAMP(6);
 #ifdef SV3D_TRACE
@@ -1007,7 +1016,10 @@ __global__ __launch_bounds__(kThreads) void raster_backward_kernel(
         bool valid;
     };
     const size_t plane = (size_t)H * H;
-    const float *grad_b = grad_rgba + (size_t)b * (NC + 1) * plane;     // colour + alpha planes of image b
+    const bool only_alpha = MODE == SV3D_TEX_NONE && P.alpha_only;
+    // colour + alpha planes of image b, or its alpha plane alone
+    const float *grad_b = grad_rgba + (size_t)b * (only_alpha ? 1 : NC + 1) * plane;
+    const size_t alpha_plane = only_alpha ? 0 : NC * plane;
     auto fetch = [&]() {                            // inputs of the pixel at the current (rx, ry)
         PixIn in;
         in.valid = ry_f < bh_f;
@@ -1026,7 +1038,7 @@ __global__ __launch_bounds__(kThreads) void raster_backward_kernel(
         in.ssum = in.m = 0.f;
 #pragma unroll
         for (int c = 0; c < NC; ++c) in.col[c] = in.gch[c] = 0.f;
-        in.ga = grad_b[gpix + NC * plane];
+        in.ga = grad_b[gpix + alpha_plane];
         if (MODE == SV3D_TEX_NONE) {
             in.A = saved_b[pix];
         } else if (NC == 3) {
@@ -1137,8 +1149,8 @@ __global__ __launch_bounds__(kThreads) void raster_backward_kernel(
                 const float gw2 = (g.w2 > 0.f && g.w2 < 1.f) ? (gn2 - dotn) * d.rs : 0.f;
                 // grad_w_j = (-e_{j+1}.y, e_{j+1}.x) / det; moving vertex i shifts the pixel's
                 // barycentrics like moving the pixel by -w_i
-                const float Vx = -r.inv_det * (gw0 * r.e1y + gw1 * r.e2y + gw2 * r.e0y);
-                const float Vy = r.inv_det * (gw0 * r.e1x + gw1 * r.e2x + gw2 * r.e0x);
+                const float Vx = -(gw0 * r.f1y + gw1 * r.f2y + gw2 * r.f0y);
+                const float Vy = gw0 * r.f1x + gw1 * r.f2x + gw2 * r.f0x;
                 acc[0] -= g.w0 * Vx; acc[1] -= g.w0 * Vy;
                 acc[3] -= g.w1 * Vx; acc[4] -= g.w1 * Vy;
                 acc[6] -= g.w2 * Vx; acc[7] -= g.w2 * Vy;
@@ -1245,6 +1257,8 @@ int make_dev_params(const sv3d_raster_params *p, DevParams &d)
     if (!(p->far_plane > p->near_plane)) return SV3D_ERR_INVALID_ARG;
     if (p->texture_batch < 0 || (p->texture_batch > 0 && p->batch % p->texture_batch != 0))
         return SV3D_ERR_INVALID_ARG;
+    if ((p->alpha_only != 0 && p->alpha_only != 1) || (p->alpha_only && p->texture_mode != SV3D_TEX_NONE))
+        return SV3D_ERR_INVALID_ARG;
     if (p->raster_size > 4096 || p->batch > 65535) return SV3D_ERR_UNSUPPORTED;
     if ((long)p->batch * p->num_faces > 0x7fffffffL / 4) return SV3D_ERR_UNSUPPORTED;
     if (p->texture_mode == SV3D_TEX_SURFACE && p->texture_res > 36) return SV3D_ERR_UNSUPPORTED;
@@ -1266,6 +1280,7 @@ int make_dev_params(const sv3d_raster_params *p, DevParams &d)
     d.ssum0 = (float)exp((double)p->eps / (double)p->gamma);
     d.inv_S = (float)(1.0 / (double)p->raster_size);
     d.alpha_fast = (double)p->dist_eps / (1.0 - (double)p->dist_eps) < 2.9e-8;   // below half an ulp of 1
+    d.alpha_only = p->alpha_only;
     return SV3D_OK;
 }
 

@@ -35,6 +35,7 @@ class RasterParams(ctypes.Structure):
         ("background", ctypes.c_float * 3),
         ("near_plane", ctypes.c_float), ("far_plane", ctypes.c_float), ("eps", ctypes.c_float),
         ("sigma", ctypes.c_float), ("dist_eps", ctypes.c_float), ("gamma", ctypes.c_float),
+        ("alpha_only", ctypes.c_int32),
     ]
 
 
@@ -107,7 +108,7 @@ def check(status, what):
 
 
 def make_params(batch, num_faces, raster_size, aa, texture_mode, texture_res, double_side,
-                background, near, far, eps, sigma, dist_eps, gamma):
+                background, near, far, eps, sigma, dist_eps, gamma, alpha_only=False):
     p = RasterParams()
     p.batch, p.num_faces, p.raster_size, p.aa = int(batch), int(num_faces), int(raster_size), int(aa)
     p.texture_mode, p.texture_res = int(texture_mode), int(texture_res)
@@ -115,6 +116,7 @@ def make_params(batch, num_faces, raster_size, aa, texture_mode, texture_res, do
     p.background[0], p.background[1], p.background[2] = (float(c) for c in background)
     p.near_plane, p.far_plane, p.eps = float(near), float(far), float(eps)
     p.sigma, p.dist_eps, p.gamma = float(sigma), float(dist_eps), float(gamma)
+    p.alpha_only = int(bool(alpha_only))
     return p
 
 

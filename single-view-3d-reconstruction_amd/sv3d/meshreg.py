@@ -92,15 +92,19 @@ def _check_vertices(x):
         raise ValueError("vertices must be a non-empty [B,V,3] tensor, got %s" % (tuple(x.shape),))
 
 
-def _check_i32(t, name):
+def _check_i32(t, name, like=None):
     if t.dtype != torch.int32 or not t.is_contiguous():
         raise ValueError("%s must be a contiguous int32 tensor" % name)
+    if like is not None and t.device != like.device:
+        # a host pointer handed to a kernel is a GPU memory fault, not an exception: refuse it here
+        raise RuntimeError("%s is on %s but the vertices are on %s (move the loss module to the GPU)"
+                           % (name, t.device, like.device))
 
 
 def _laplacian_launch(vertices, row_start, nbr):
     _check_vertices(vertices)
-    _check_i32(row_start, "row_start")
-    _check_i32(nbr, "nbr")
+    _check_i32(row_start, "row_start", vertices)
+    _check_i32(nbr, "nbr", vertices)
     x = _f32c(vertices)
     B, V = x.shape[0], x.shape[1]
     if row_start.numel() != V + 1:
@@ -127,7 +131,7 @@ def _(vertices, row_start, nbr):
 def _flatten_launch(vertices, quads, inc_start, inc, eps):
     _check_vertices(vertices)
     for t, name in ((quads, "quads"), (inc_start, "inc_start"), (inc, "inc")):
-        _check_i32(t, name)
+        _check_i32(t, name, vertices)
     x = _f32c(vertices)
     B, V, E = x.shape[0], x.shape[1], quads.shape[0]
     if quads.dim() != 2 or quads.shape[1] != 4 or E == 0:
@@ -182,8 +186,10 @@ flatten_loss_op.register_autograd(_flatten_backward, setup_context=_loss_setup_c
 def mesh_spmv_op(x: Tensor, values: Tensor, row_start: Tensor, col: Tensor,
                  values_t: Tensor, row_start_t: Tensor, col_t: Tensor) -> Tensor:
     _check_vertices(x)
-    _check_i32(row_start, "row_start")
-    _check_i32(col, "col")
+    _check_i32(row_start, "row_start", x)
+    _check_i32(col, "col", x)
+    if values.device != x.device:
+        raise RuntimeError("values are on %s but x is on %s" % (values.device, x.device))
     xs, vals = _f32c(x), _f32c(values)
     B, V, nnz = xs.shape[0], xs.shape[1], col.numel()
     if vals.dim() != 2 or vals.shape[1] != nnz or vals.shape[0] not in (1, B):

@@ -82,6 +82,8 @@ def _texture_shape(B, F, texture_mode, texture_res):
 
 
 def _check_raster_inputs(fv, tex, texture_mode, texture_res):
+    if tex is not None and tex.device != fv.device:
+        raise RuntimeError("textures are on %s, face_vertices on %s" % (tex.device, fv.device))
     if fv.dim() != 4 or fv.shape[2:] != (3, 3):
         raise ValueError("face_vertices must be [B,F,3,3], got %s" % (tuple(fv.shape),))
     if texture_mode == L.SV3D_TEX_NONE:
@@ -262,6 +264,8 @@ def soft_rasterize(face_vertices, textures=None, image_size=256, *, anti_aliasin
 
 # ---- chamfer --------------------------------------------------------------------------
 def _check_clouds(xyz1, xyz2):
+    if xyz1.device != xyz2.device:
+        raise RuntimeError("point clouds are on %s and %s" % (xyz1.device, xyz2.device))
     if xyz1.dim() != 3 or xyz2.dim() != 3 or xyz1.shape[2] != 3 or xyz2.shape[2] != 3 \
             or xyz1.shape[0] != xyz2.shape[0]:
         raise ValueError("point clouds must be [B,N,3] and [B,M,3], got %s and %s"
@@ -349,6 +353,8 @@ def face_gather_op(values: Tensor, faces: Tensor, scale: List[float], shift: Lis
     if faces.dim() != 3 or faces.shape[2] != 3 or faces.dtype != torch.int32 \
             or faces.shape[0] not in (1, values.shape[0]):
         raise ValueError("faces must be int32 [B or 1,F,3], got %s %s" % (faces.dtype, tuple(faces.shape)))
+    if faces.device != values.device:
+        raise RuntimeError("faces are on %s, values on %s" % (faces.device, values.device))
     v = _f32c(values)
     f = faces.contiguous()
     B, V, F = v.shape[0], v.shape[1], f.shape[1]
@@ -406,7 +412,16 @@ def face_gather(values, faces, scale=(1.0, 1.0, 1.0), shift=(0.0, 0.0, 0.0)):
 
 
 # ---- camera + gather, and the renderer call from the object-space mesh -----------------
+def _check_same_device(ref, **others):
+    """A tensor on another device (or on the host) would reach the kernels as a foreign pointer,
+    which faults the GPU instead of raising: refuse it here."""
+    for name, t in others.items():
+        if t is not None and t.device != ref.device:
+            raise RuntimeError("%s is on %s, expected %s" % (name, t.device, ref.device))
+
+
 def _check_mesh(vertices, cams, faces):
+    _check_same_device(vertices, cams=cams, faces=faces)
     if vertices.dim() != 3 or vertices.shape[2] != 3:
         raise ValueError("vertices must be [B,V,3], got %s" % (tuple(vertices.shape),))
     if cams.dim() != 2 or tuple(cams.shape) != (vertices.shape[0], 7):
@@ -495,6 +510,7 @@ def render_op(vertices: Tensor, cams: Tensor, faces: Tensor, textures: Optional[
     B, F = v.shape[0], f.shape[1]
     if texture_mode != L.SV3D_TEX_NONE:
         _check_textures(textures, B, F, texture_mode, texture_res)
+        _check_same_device(vertices, textures=textures)
     tex = _f32c(textures) if texture_mode != L.SV3D_TEX_NONE else None
     p = _with_texture_batch(L.make_params(B, F, raster_size, aa, texture_mode, texture_res, double_side,
                                           background, near, far, eps, sigma, dist_eps, gamma), tex)
@@ -617,6 +633,7 @@ def render(vertices, cams, faces, textures=None, image_size=256, *, offset_z=0.0
         B, F = vertices.shape[0], f32.shape[1]
         if mode != L.SV3D_TEX_NONE:
             _check_textures(textures, B, F, mode, res)
+            _check_same_device(vertices, textures=textures)
         key = (B, F, int(image_size) * aa, aa, mode, res, bool(fill_back),
                tuple(float(c) for c in background_color), float(near), float(far), float(eps),
                float(sigma_val), float(dist_eps), float(gamma_val))
@@ -649,23 +666,28 @@ def _plain(*tensors):
 _PARAM_CACHE = {}
 
 
-def _cached_params(key):
-    """(params struct, face_rec_bytes, pixel_saved_bytes) per configuration tuple."""
-    hit = _PARAM_CACHE.get(key)
+def _cached_params(key, tex, alpha_only):
+    """(params struct, face_rec_bytes, pixel_saved_bytes) per configuration tuple, texture batch and
+    output form.  A cached struct is never written to again: forward and backward calls of
+    different graphs (autograd runs backward on its own threads) may hold the same one."""
+    tb = 0 if tex is None or tex.shape[0] == key[0] else tex.shape[0]
+    full = (key, tb, alpha_only)
+    hit = _PARAM_CACHE.get(full)
     if hit is None:
-        p = L.make_params(*key)
+        p = L.make_params(*key, alpha_only=alpha_only)
+        p.texture_batch = tb
         rec_b, saved_b, _ = L.raster_sizes(p)
         hit = (p, rec_b, saved_b)
         if len(_PARAM_CACHE) > 256:
             _PARAM_CACHE.clear()
-        _PARAM_CACHE[key] = hit
+        _PARAM_CACHE[full] = hit
     return hit
 
 
 def _raster_backward_call(p, g, tex, rec, saved, need_tex, B, F):
     gfv = torch.empty((B, F, 3, 3), dtype=torch.float32, device=g.device)
     gtex = _grad_textures_buffer(tex, B) if (tex is not None and need_tex) else None
-    L.check(L.lib().sv3d_raster_backward(ctypes.byref(_with_texture_batch(p, tex)), _ptr(tex), _ptr(rec),
+    L.check(L.lib().sv3d_raster_backward(ctypes.byref(p), _ptr(tex), _ptr(rec),
                                          _ptr(saved), _ptr(g), _ptr(gfv), _ptr(gtex), None, ctypes.c_size_t(0),
                                          _stream(g)), "sv3d_raster_backward")
     return gfv, (_fold_grad_textures(gtex, tex) if gtex is not None else None)
@@ -680,12 +702,15 @@ class _RenderFn(torch.autograd.Function):
         # geom: vertices [B,V,3] when cams is given, else face_vertices [B,F,3,3]
         x = _f32c(geom)
         tex = _f32c(textures) if key[4] != L.SV3D_TEX_NONE else None
-        p, rec_b, saved_b = _cached_params(key)
-        _with_texture_batch(p, tex)
+        # alpha_only without colours: the kernels write (and later read the gradient of) the alpha
+        # plane alone; with colours the full image is rendered and its last plane handed out
+        plane_only = alpha_only and key[4] == L.SV3D_TEX_NONE
+        p, rec_b, saved_b = _cached_params(key, tex, plane_only)
         B, S, aa = key[0], key[2], key[3]
         dev = x.device
         with _on(dev):
-            rgba = torch.empty((B, _channels(key[4]), S // aa, S // aa), dtype=torch.float32, device=dev)
+            rgba = torch.empty((B, 1 if plane_only else _channels(key[4]), S // aa, S // aa),
+                               dtype=torch.float32, device=dev)
             rec = torch.empty(rec_b // 4, dtype=torch.float32, device=dev)
             saved = torch.empty(saved_b // 4, dtype=torch.float32, device=dev)
             if cams is not None:
@@ -700,7 +725,7 @@ class _RenderFn(torch.autograd.Function):
                                                     _ptr(saved), _stream(x)), "sv3d_raster_forward")
                 ctx.save_for_backward(rec, saved, tex)
         ctx.key, ctx.mesh_args, ctx.has_mesh = key, mesh_args, cams is not None
-        ctx.alpha_only = alpha_only
+        ctx.alpha_only, ctx.plane_only = alpha_only, plane_only
         ctx.dtypes = (geom.dtype, cams.dtype if cams is not None else None,
                       textures.dtype if textures is not None else None)
         # alpha_only: the silhouette plane itself is the output, so that autograd hands its gradient
@@ -710,14 +735,14 @@ class _RenderFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_rgba):
         key = ctx.key
-        p, _, _ = _cached_params(key)
-        if ctx.alpha_only:
-            # only the alpha plane of the gradient is read when there are no colours
-            full = torch.empty((key[0], _channels(key[4]), key[2] // key[3], key[2] // key[3]),
+        tex_saved = ctx.saved_tensors[-1]
+        p, _, _ = _cached_params(key, tex_saved, ctx.plane_only)
+        if ctx.plane_only:
+            g = _f32c(grad_rgba)                # [B,H,W] is the [B,1,H,W] the kernel reads
+        elif ctx.alpha_only:
+            full = torch.zeros((key[0], _channels(key[4]), key[2] // key[3], key[2] // key[3]),
                                dtype=torch.float32, device=grad_rgba.device)
             full[:, -1].copy_(grad_rgba)
-            if key[4] != L.SV3D_TEX_NONE:
-                full[:, :-1].zero_()
             g = full
         else:
             g = _f32c(grad_rgba)
@@ -782,6 +807,8 @@ def face_gather_n_op(values: Tensor, faces: Tensor) -> Tensor:
     if faces.dim() != 3 or faces.shape[2] != 3 or faces.dtype != torch.int32 \
             or faces.shape[0] not in (1, values.shape[0]):
         raise ValueError("faces must be int32 [B or 1,F,3], got %s %s" % (faces.dtype, tuple(faces.shape)))
+    if faces.device != values.device:
+        raise RuntimeError("faces are on %s, values on %s" % (faces.device, values.device))
     v, f = _f32c(values), faces.contiguous()
     B, V, C, F = v.shape[0], v.shape[1], v.shape[2], f.shape[1]
     with _on(v.device):

@@ -13,8 +13,8 @@ MAX_CHANNELS = 4
 
 
 def _check_sample_args(images, flow):
-    if not (images.is_cuda and flow.is_cuda):
-        raise RuntimeError("sv3d.texture_sample runs on the GPU only")
+    if not (images.is_cuda and flow.is_cuda) or images.device != flow.device:
+        raise RuntimeError("sv3d.texture_sample runs on the GPU only, images and flow on one device")
     if images.dim() != 4 or not 1 <= images.shape[1] <= MAX_CHANNELS or images.shape[2] < 1 or images.shape[3] < 1:
         raise ValueError("images must be [B,C,H,W] with C <= %d, got %s" % (MAX_CHANNELS, tuple(images.shape)))
     if flow.dim() != 3 or flow.shape[2] != 2 or flow.shape[0] != images.shape[0] or flow.shape[1] == 0:

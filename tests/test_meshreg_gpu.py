@@ -69,7 +69,9 @@ def test_flatten_edge_list_hand_computed_tetrahedron():
 def test_flatten_loss_tetrahedron_on_the_gpu():
     import soft_renderer as sr
     x = torch.from_numpy(TETRAHEDRON_VERTS).float()[None].cuda()
-    got = sr.FlattenLoss(torch.from_numpy(TETRAHEDRON))(x)
+    with pytest.raises(RuntimeError):                      # index tables left on the host: refused, not a fault
+        sr.FlattenLoss(torch.from_numpy(TETRAHEDRON))(x)
+    got = sr.FlattenLoss(torch.from_numpy(TETRAHEDRON)).cuda()(x)
     want = mo.flatten_loss(torch.from_numpy(TETRAHEDRON_VERTS)[None], TETRAHEDRON)
     assert abs(float(got) - float(want)) < 1e-5 * float(want) and abs(float(got) - 80.0 / 9.0) < 1e-4
 

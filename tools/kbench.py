@@ -55,6 +55,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--iters", type=int, default=30)
     ap.add_argument("--json", default="")
+    ap.add_argument("--alpha-only", type=int, default=0, help="silhouette configs: alpha plane alone")
     args = ap.parse_args()
 
     from sv3d import _lib as L, workmodel
@@ -78,7 +79,8 @@ def main():
         fv, tex, grad = bench.build_inputs(ns, dev, seed=1000)
         S = img * (2 if aa else 1)
         m = {"none": 0, "surface": 1, "vertex": 2, "vertex8": 3}[mode]
-        p = L.make_params(B, fv.shape[1], S, 2 if aa else 1, m, T, True, (0, 0, 0), 1, 100, 1e-3, sigma, 1e-10, 1e-4)
+        p = L.make_params(B, fv.shape[1], S, 2 if aa else 1, m, T, True, (0, 0, 0), 1, 100, 1e-3, sigma, 1e-10, 1e-4,
+                          alpha_only=bool(args.alpha_only) and mode == "none")
         # every library sizes its own buffers (builds may differ in what they keep there): take the
         # largest requirement over the libraries under test, never the in-tree library's alone
         rec_b = saved_b = ws_b = 0
