@@ -1,0 +1,826 @@
+// PyTorch operators `sv3d::*` over the C ABI of libsv3d_hip.so (include/sv3d_hip.h), registered
+// from C++ so that a call costs a dispatcher hop instead of a Python-level op definition:
+//
+//   soft_rasterize / soft_rasterize_backward   soft_renderer's `soft_rasterize`, reached from
+//                                              nnutils/softras.py:64,75,77
+//   render / render_backward                   the whole renderer call of nnutils/softras.py:57-77
+//                                              from the object-space mesh
+//   chamfer_nn / chamfer_nn_backward           ChamferDistance as called at nnutils/loss_utils.py:85-86
+//   face_gather / face_scatter                 sr.Mesh's `vertices[faces]` + affine pre-stage
+//   project_gather / project_scatter           camera + flip + gather, nnutils/softras.py:58-61
+//   face_gather_n / face_scatter_n             per-vertex part maps (main.py:422-426) per face corner
+//
+// Every operator has a GPU kernel (key CUDA, which is HIP in a ROCm build of PyTorch), a Meta
+// kernel (shapes only: fake-tensor tracing) and, for the differentiable ones, an Autograd kernel.
+// There is no CPU kernel: CPU tensors fail in the dispatcher.  Inputs of other floating types
+// (autocast regions hand over fp16) are computed in fp32 and gradients are returned in the
+// inputs' types.  torch is used for device memory, streams and autograd plumbing only.
+#include <ATen/ATen.h>
+#include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>
+#include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
+#include <torch/autograd.h>
+#include <torch/library.h>
+
+#include <string>
+#include <tuple>
+#include <vector>
+
+#include "sv3d_hip.h"
+
+namespace {
+
+using at::Tensor;
+using c10::optional;
+using torch::autograd::AutogradContext;
+using torch::autograd::variable_list;
+using IntList = at::IntArrayRef;
+using FloatList = at::ArrayRef<double>;
+
+// ---- small helpers ---------------------------------------------------------------------------
+void check_status(int st, const char *what)
+{
+    TORCH_CHECK(st == SV3D_OK, what, " failed: ", sv3d_strerror(st), " (status ", st, ")");
+}
+
+Tensor f32c(const Tensor &t)
+{
+    Tensor r = t.detach();
+    if (r.scalar_type() != at::kFloat) r = r.to(at::kFloat);
+    return r.contiguous();
+}
+
+struct Launch {
+    c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard;
+    void *stream;
+    explicit Launch(const Tensor &t) : guard(t.device())
+    {
+        stream = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(t.device().index()).stream();
+    }
+};
+
+const float *fptr(const optional<Tensor> &t) { return t.has_value() && t->defined() && t->numel() > 0 ? t->data_ptr<float>() : nullptr; }
+const float *fptr(const Tensor &t) { return t.defined() && t.numel() > 0 ? t.data_ptr<float>() : nullptr; }
+float *fptr_mut(Tensor &t) { return t.defined() && t.numel() > 0 ? t.data_ptr<float>() : nullptr; }
+
+void same_device(const Tensor &ref, const Tensor &t, const char *name)
+{
+    // a tensor on the host or on another GPU would reach the kernels as a foreign pointer
+    TORCH_CHECK(t.device() == ref.device(), name, " is on ", t.device(), ", expected ", ref.device());
+}
+
+// icfg: raster_size, aa, texture_mode, texture_res, double_side, alpha_only
+// fcfg: background r g b, near, far, eps, sigma, dist_eps, gamma
+sv3d_raster_params make_params(int64_t B, int64_t F, IntList icfg, FloatList fcfg, const optional<Tensor> &tex)
+{
+    TORCH_CHECK_VALUE(icfg.size() == 6 && fcfg.size() == 9, "raster configuration must hold 6 integers and 9 floats");
+    sv3d_raster_params p;
+    p.batch = (int32_t)B;
+    p.num_faces = (int32_t)F;
+    p.raster_size = (int32_t)icfg[0];
+    p.aa = (int32_t)icfg[1];
+    p.texture_mode = (int32_t)icfg[2];
+    p.texture_res = (int32_t)icfg[3];
+    p.double_side = icfg[4] ? 1 : 0;
+    p.alpha_only = (icfg[5] && icfg[2] == SV3D_TEX_NONE) ? 1 : 0;
+    p.texture_batch = 0;
+    if (tex.has_value() && tex->defined() && icfg[2] != SV3D_TEX_NONE && tex->size(0) != B)
+        p.texture_batch = (int32_t)tex->size(0);
+    for (int i = 0; i < 3; ++i) p.background[i] = (float)fcfg[i];
+    p.near_plane = (float)fcfg[3];
+    p.far_plane = (float)fcfg[4];
+    p.eps = (float)fcfg[5];
+    p.sigma = (float)fcfg[6];
+    p.dist_eps = (float)fcfg[7];
+    p.gamma = (float)fcfg[8];
+    return p;
+}
+
+int64_t image_planes(const sv3d_raster_params &p)
+{
+    if (p.alpha_only) return 1;
+    return p.texture_mode == SV3D_TEX_VERTEX8 ? 9 : 4;
+}
+
+void check_textures(const optional<Tensor> &tex, int64_t B, int64_t F, int64_t mode, int64_t res)
+{
+    if (mode == SV3D_TEX_NONE) return;
+    TORCH_CHECK_VALUE(tex.has_value() && tex->defined(), "textures required for texture_mode ", mode);
+    const int64_t d2 = mode == SV3D_TEX_SURFACE ? res * res : 3;
+    const int64_t d3 = mode == SV3D_TEX_VERTEX8 ? 8 : 3;
+    TORCH_CHECK_VALUE(tex->dim() == 4 && tex->size(1) == F && tex->size(2) == d2 && tex->size(3) == d3 &&
+                          tex->size(0) >= 1 && B % tex->size(0) == 0,
+                      "textures must be [", B, " or a divisor of it, ", F, ", ", d2, ", ", d3, "], got ", tex->sizes());
+}
+
+void check_mesh(const Tensor &vertices, const Tensor &cams, const Tensor &faces)
+{
+    TORCH_CHECK_VALUE(vertices.dim() == 3 && vertices.size(2) == 3 && vertices.size(0) > 0 && vertices.size(1) > 0,
+                      "vertices must be [B,V,3], got ", vertices.sizes());
+    TORCH_CHECK_VALUE(cams.dim() == 2 && cams.size(0) == vertices.size(0) && cams.size(1) == 7,
+                      "cams must be [B,7], got ", cams.sizes());
+    TORCH_CHECK_VALUE(faces.dim() == 3 && faces.size(2) == 3 && faces.scalar_type() == at::kInt &&
+                          (faces.size(0) == 1 || faces.size(0) == vertices.size(0)) && faces.size(1) > 0,
+                      "faces must be int32 [B or 1,F,3], got ", faces.scalar_type(), " ", faces.sizes());
+    same_device(vertices, cams, "cams");
+    same_device(vertices, faces, "faces");
+}
+
+sv3d_mesh_input mesh_input(const Tensor &v, const Tensor &c, const Tensor &f, FloatList mesh_cfg, bool with_shift)
+{
+    TORCH_CHECK_VALUE(mesh_cfg.size() == 7, "mesh configuration must hold offset_z, scale[3], shift[3]");
+    sv3d_mesh_input m;
+    m.vertices = v.data_ptr<float>();
+    m.cams = c.data_ptr<float>();
+    m.faces = f.data_ptr<int32_t>();
+    m.num_vertices = (int32_t)v.size(1);
+    m.faces_batch = (int32_t)f.size(0);
+    m.offset_z = (float)mesh_cfg[0];
+    for (int i = 0; i < 3; ++i) {
+        m.scale[i] = (float)mesh_cfg[1 + i];
+        m.shift[i] = with_shift ? (float)mesh_cfg[4 + i] : 0.f;
+    }
+    return m;
+}
+
+struct RasterBuffers {
+    Tensor rgba, rec, saved;
+};
+
+RasterBuffers alloc_raster(const sv3d_raster_params &p, const at::TensorOptions &opt)
+{
+    size_t rec_b = 0, saved_b = 0, ws_b = 0;
+    const int st = sv3d_raster_sizes(&p, &rec_b, &saved_b, &ws_b);
+    TORCH_CHECK(st == SV3D_OK, "sv3d_raster_sizes failed: ", sv3d_strerror(st), " (status ", st, ")");
+    const int64_t H = p.raster_size / p.aa;
+    RasterBuffers b;
+    b.rgba = at::empty({p.batch, image_planes(p), H, H}, opt);
+    b.rec = at::empty({(int64_t)(rec_b / 4)}, opt);
+    b.saved = at::empty({(int64_t)(saved_b / 4)}, opt);
+    return b;
+}
+
+Tensor fold_grad_textures(const Tensor &gtex, const Tensor &tex)
+{
+    // per-image gradients summed over the images that shared a texture set
+    if (gtex.size(0) == tex.size(0)) return gtex;
+    std::vector<int64_t> shape = {gtex.size(0) / tex.size(0)};
+    for (auto s : tex.sizes()) shape.push_back(s);
+    return gtex.view(shape).sum(0);
+}
+
+// ---- soft_rasterize ---------------------------------------------------------------------------
+std::tuple<Tensor, Tensor, Tensor> soft_rasterize_gpu(const Tensor &face_vertices, const optional<Tensor> &textures,
+                                                      IntList icfg, FloatList fcfg)
+{
+    TORCH_CHECK_VALUE(face_vertices.dim() == 4 && face_vertices.size(2) == 3 && face_vertices.size(3) == 3 &&
+                          face_vertices.size(0) > 0 && face_vertices.size(1) > 0,
+                      "face_vertices must be [B,F,3,3], got ", face_vertices.sizes());
+    const int64_t B = face_vertices.size(0), F = face_vertices.size(1);
+    TORCH_CHECK_VALUE(icfg.size() == 6, "raster configuration must hold 6 integers");
+    check_textures(textures, B, F, icfg[2], icfg[3]);
+    const Tensor fv = f32c(face_vertices);
+    Tensor tex;
+    if (icfg[2] != SV3D_TEX_NONE) {
+        same_device(fv, *textures, "textures");
+        tex = f32c(*textures);
+    }
+    const sv3d_raster_params p = make_params(B, F, icfg, fcfg, textures);
+    Launch L(fv);
+    RasterBuffers b = alloc_raster(p, fv.options());
+    check_status(sv3d_raster_forward(&p, fv.data_ptr<float>(), fptr(tex), b.rgba.data_ptr<float>(),
+                                     b.rec.data_ptr<float>(), b.saved.data_ptr<float>(), L.stream),
+                 "sv3d_raster_forward");
+    return {b.rgba, b.rec, b.saved};
+}
+
+std::tuple<Tensor, Tensor, Tensor> raster_meta(const Tensor &like, int64_t B, int64_t F, IntList icfg, FloatList fcfg,
+                                               const optional<Tensor> &textures)
+{
+    const sv3d_raster_params p = make_params(B, F, icfg, fcfg, textures);
+    size_t rec_b = 0, saved_b = 0, ws_b = 0;
+    check_status(sv3d_raster_sizes(&p, &rec_b, &saved_b, &ws_b), "sv3d_raster_sizes");
+    const int64_t H = p.raster_size / p.aa;
+    const auto opt = like.options().dtype(at::kFloat);
+    return {at::empty({B, image_planes(p), H, H}, opt), at::empty({(int64_t)(rec_b / 4)}, opt),
+            at::empty({(int64_t)(saved_b / 4)}, opt)};
+}
+
+std::tuple<Tensor, Tensor, Tensor> soft_rasterize_meta(const Tensor &face_vertices, const optional<Tensor> &textures,
+                                                       IntList icfg, FloatList fcfg)
+{
+    return raster_meta(face_vertices, face_vertices.size(0), face_vertices.size(1), icfg, fcfg, textures);
+}
+
+// shape = (batch, num_faces)
+std::tuple<Tensor, Tensor> soft_rasterize_backward_gpu(const Tensor &grad_rgba, const optional<Tensor> &textures,
+                                                       const Tensor &face_rec, const Tensor &pixel_saved,
+                                                       IntList shape, IntList icfg, FloatList fcfg, bool need_textures)
+{
+    TORCH_CHECK_VALUE(shape.size() == 2 && icfg.size() == 6, "shape must be (batch, faces)");
+    const int64_t B = shape[0], F = shape[1];
+    const Tensor g = f32c(grad_rgba);
+    Tensor tex;
+    if (icfg[2] != SV3D_TEX_NONE) tex = f32c(*textures);
+    const sv3d_raster_params p = make_params(B, F, icfg, fcfg, textures);
+    TORCH_CHECK_VALUE(g.numel() == B * image_planes(p) * (p.raster_size / p.aa) * (p.raster_size / p.aa),
+                      "grad_rgba does not match the rendered image, got ", g.sizes());
+    Launch L(g);
+    Tensor gfv = at::empty({B, F, 3, 3}, g.options());
+    Tensor gtex = at::empty({0}, g.options());
+    if (tex.defined() && need_textures) {
+        std::vector<int64_t> s = tex.sizes().vec();
+        s[0] = B;
+        gtex = at::empty(s, g.options());
+    }
+    check_status(sv3d_raster_backward(&p, fptr(tex), face_rec.data_ptr<float>(), pixel_saved.data_ptr<float>(),
+                                      g.data_ptr<float>(), gfv.data_ptr<float>(), fptr_mut(gtex), nullptr, 0,
+                                      L.stream),
+                 "sv3d_raster_backward");
+    if (tex.defined() && need_textures) gtex = fold_grad_textures(gtex, tex);
+    return {gfv, gtex};
+}
+
+std::tuple<Tensor, Tensor> soft_rasterize_backward_meta(const Tensor &grad_rgba, const optional<Tensor> &textures,
+                                                        const Tensor &face_rec, const Tensor &pixel_saved,
+                                                        IntList shape, IntList icfg, FloatList fcfg, bool need_textures)
+{
+    const auto opt = grad_rgba.options().dtype(at::kFloat);
+    Tensor gtex = (textures.has_value() && textures->defined() && need_textures && icfg[2] != SV3D_TEX_NONE)
+                      ? at::empty(textures->sizes(), opt)
+                      : at::empty({0}, opt);
+    return {at::empty({shape[0], shape[1], 3, 3}, opt), gtex};
+}
+
+// ---- render -------------------------------------------------------------------------------------
+std::tuple<Tensor, Tensor, Tensor> render_gpu(const Tensor &vertices, const Tensor &cams, const Tensor &faces,
+                                              const optional<Tensor> &textures, FloatList mesh_cfg, IntList icfg,
+                                              FloatList fcfg)
+{
+    check_mesh(vertices, cams, faces);
+    const int64_t B = vertices.size(0), F = faces.size(1);
+    TORCH_CHECK_VALUE(icfg.size() == 6, "raster configuration must hold 6 integers");
+    check_textures(textures, B, F, icfg[2], icfg[3]);
+    const Tensor v = f32c(vertices), c = f32c(cams), f = faces.contiguous();
+    Tensor tex;
+    if (icfg[2] != SV3D_TEX_NONE) {
+        same_device(v, *textures, "textures");
+        tex = f32c(*textures);
+    }
+    const sv3d_raster_params p = make_params(B, F, icfg, fcfg, textures);
+    const sv3d_mesh_input m = mesh_input(v, c, f, mesh_cfg, true);
+    Launch L(v);
+    RasterBuffers b = alloc_raster(p, v.options());
+    check_status(sv3d_render_forward(&p, &m, fptr(tex), nullptr, b.rgba.data_ptr<float>(), b.rec.data_ptr<float>(),
+                                     b.saved.data_ptr<float>(), L.stream),
+                 "sv3d_render_forward");
+    return {b.rgba, b.rec, b.saved};
+}
+
+std::tuple<Tensor, Tensor, Tensor> render_meta(const Tensor &vertices, const Tensor &cams, const Tensor &faces,
+                                               const optional<Tensor> &textures, FloatList mesh_cfg, IntList icfg,
+                                               FloatList fcfg)
+{
+    return raster_meta(vertices, vertices.size(0), faces.size(1), icfg, fcfg, textures);
+}
+
+std::tuple<Tensor, Tensor, Tensor> render_backward_gpu(const Tensor &grad_rgba, const Tensor &vertices,
+                                                       const Tensor &cams, const Tensor &faces,
+                                                       const optional<Tensor> &textures, const Tensor &face_rec,
+                                                       const Tensor &pixel_saved, FloatList mesh_cfg, IntList icfg,
+                                                       FloatList fcfg, bool need_textures)
+{
+    const Tensor g = f32c(grad_rgba), v = f32c(vertices), c = f32c(cams), f = faces.contiguous();
+    const int64_t B = v.size(0), F = f.size(1);
+    TORCH_CHECK_VALUE(icfg.size() == 6, "raster configuration must hold 6 integers");
+    Tensor tex;
+    if (icfg[2] != SV3D_TEX_NONE) tex = f32c(*textures);
+    const sv3d_raster_params p = make_params(B, F, icfg, fcfg, textures);
+    TORCH_CHECK_VALUE(g.numel() == B * image_planes(p) * (p.raster_size / p.aa) * (p.raster_size / p.aa),
+                      "grad_rgba does not match the rendered image, got ", g.sizes());
+    Launch L(g);
+    Tensor gfv = at::empty({B, F, 3, 3}, g.options());
+    Tensor gtex = at::empty({0}, g.options());
+    if (tex.defined() && need_textures) {
+        std::vector<int64_t> s = tex.sizes().vec();
+        s[0] = B;
+        gtex = at::empty(s, g.options());
+    }
+    Tensor gv = at::empty_like(v), gc = at::empty_like(c);
+    check_status(sv3d_raster_backward(&p, fptr(tex), face_rec.data_ptr<float>(), pixel_saved.data_ptr<float>(),
+                                      g.data_ptr<float>(), gfv.data_ptr<float>(), fptr_mut(gtex), nullptr, 0,
+                                      L.stream),
+                 "sv3d_raster_backward");
+    const sv3d_mesh_input m = mesh_input(v, c, f, mesh_cfg, false);
+    check_status(sv3d_project_scatter(&m, (int32_t)B, (int32_t)F, gfv.data_ptr<float>(), gv.data_ptr<float>(),
+                                      gc.data_ptr<float>(), L.stream),
+                 "sv3d_project_scatter");
+    if (tex.defined() && need_textures) gtex = fold_grad_textures(gtex, tex);
+    return {gv, gc, gtex};
+}
+
+std::tuple<Tensor, Tensor, Tensor> render_backward_meta(const Tensor &grad_rgba, const Tensor &vertices,
+                                                        const Tensor &cams, const Tensor &faces,
+                                                        const optional<Tensor> &textures, const Tensor &face_rec,
+                                                        const Tensor &pixel_saved, FloatList mesh_cfg, IntList icfg,
+                                                        FloatList fcfg, bool need_textures)
+{
+    const auto opt = grad_rgba.options().dtype(at::kFloat);
+    Tensor gtex = (textures.has_value() && textures->defined() && need_textures && icfg[2] != SV3D_TEX_NONE)
+                      ? at::empty(textures->sizes(), opt)
+                      : at::empty({0}, opt);
+    return {at::empty(vertices.sizes(), opt), at::empty(cams.sizes(), opt), gtex};
+}
+
+// ---- chamfer -----------------------------------------------------------------------------------
+void check_clouds(const Tensor &a, const Tensor &b)
+{
+    TORCH_CHECK_VALUE(a.dim() == 3 && b.dim() == 3 && a.size(2) == 3 && b.size(2) == 3 && a.size(0) == b.size(0),
+                      "point clouds must be [B,N,3] and [B,M,3], got ", a.sizes(), " and ", b.sizes());
+    TORCH_CHECK_VALUE(a.size(0) > 0 && a.size(1) > 0 && b.size(1) > 0, "empty point cloud");
+}
+
+std::tuple<Tensor, Tensor, Tensor, Tensor> chamfer_nn_gpu(const Tensor &xyz1, const Tensor &xyz2)
+{
+    check_clouds(xyz1, xyz2);
+    same_device(xyz1, xyz2, "xyz2");
+    const Tensor a = f32c(xyz1), b = f32c(xyz2);
+    const int64_t B = a.size(0), N = a.size(1), M = b.size(1);
+    Launch L(a);
+    Tensor d1 = at::empty({B, N}, a.options()), d2 = at::empty({B, M}, a.options());
+    Tensor i1 = at::empty({B, N}, a.options().dtype(at::kInt)), i2 = at::empty({B, M}, a.options().dtype(at::kInt));
+    check_status(sv3d_chamfer_forward(a.data_ptr<float>(), b.data_ptr<float>(), (int32_t)B, (int32_t)N, (int32_t)M,
+                                      d1.data_ptr<float>(), d2.data_ptr<float>(), i1.data_ptr<int32_t>(),
+                                      i2.data_ptr<int32_t>(), L.stream),
+                 "sv3d_chamfer_forward");
+    return {d1, d2, i1, i2};
+}
+
+std::tuple<Tensor, Tensor, Tensor, Tensor> chamfer_nn_meta(const Tensor &xyz1, const Tensor &xyz2)
+{
+    check_clouds(xyz1, xyz2);
+    const int64_t B = xyz1.size(0), N = xyz1.size(1), M = xyz2.size(1);
+    const auto f = xyz1.options().dtype(at::kFloat), i = xyz1.options().dtype(at::kInt);
+    return {at::empty({B, N}, f), at::empty({B, M}, f), at::empty({B, N}, i), at::empty({B, M}, i)};
+}
+
+std::tuple<Tensor, Tensor> chamfer_nn_backward_gpu(const Tensor &xyz1, const Tensor &xyz2,
+                                                   const optional<Tensor> &grad_dist1,
+                                                   const optional<Tensor> &grad_dist2, const Tensor &idx1,
+                                                   const Tensor &idx2, bool need1, bool need2)
+{
+    const Tensor a = f32c(xyz1), b = f32c(xyz2);
+    const int64_t B = a.size(0), N = a.size(1), M = b.size(1);
+    Tensor gd1, gd2;
+    if (grad_dist1.has_value() && grad_dist1->defined()) gd1 = f32c(*grad_dist1);
+    if (grad_dist2.has_value() && grad_dist2->defined()) gd2 = f32c(*grad_dist2);
+    Launch L(a);
+    Tensor g1 = need1 ? at::empty_like(a) : at::empty({0}, a.options());
+    Tensor g2 = need2 ? at::empty_like(b) : at::empty({0}, a.options());
+    check_status(sv3d_chamfer_backward(a.data_ptr<float>(), b.data_ptr<float>(), (int32_t)B, (int32_t)N, (int32_t)M,
+                                       fptr(gd1), fptr(gd2), idx1.data_ptr<int32_t>(), idx2.data_ptr<int32_t>(),
+                                       fptr_mut(g1), fptr_mut(g2), L.stream),
+                 "sv3d_chamfer_backward");
+    return {g1, g2};
+}
+
+std::tuple<Tensor, Tensor> chamfer_nn_backward_meta(const Tensor &xyz1, const Tensor &xyz2,
+                                                    const optional<Tensor> &, const optional<Tensor> &,
+                                                    const Tensor &, const Tensor &, bool need1, bool need2)
+{
+    const auto opt = xyz1.options().dtype(at::kFloat);
+    return {need1 ? at::empty(xyz1.sizes(), opt) : at::empty({0}, opt),
+            need2 ? at::empty(xyz2.sizes(), opt) : at::empty({0}, opt)};
+}
+
+// ---- gathers ------------------------------------------------------------------------------------
+void check_faces(const Tensor &values, const Tensor &faces)
+{
+    TORCH_CHECK_VALUE(faces.dim() == 3 && faces.size(2) == 3 && faces.scalar_type() == at::kInt &&
+                          (faces.size(0) == 1 || faces.size(0) == values.size(0)) && faces.size(1) > 0,
+                      "faces must be int32 [B or 1,F,3], got ", faces.scalar_type(), " ", faces.sizes());
+    same_device(values, faces, "faces");
+}
+
+void float3(FloatList v, float out[3], const char *name)
+{
+    TORCH_CHECK_VALUE(v.size() == 3, name, " must hold 3 floats");
+    for (int i = 0; i < 3; ++i) out[i] = (float)v[i];
+}
+
+Tensor face_gather_gpu(const Tensor &values, const Tensor &faces, FloatList scale, FloatList shift)
+{
+    TORCH_CHECK_VALUE(values.dim() == 3 && values.size(2) == 3 && values.size(0) > 0 && values.size(1) > 0,
+                      "values must be [B,V,3], got ", values.sizes());
+    check_faces(values, faces);
+    const Tensor v = f32c(values), f = faces.contiguous();
+    float sc[3], sh[3];
+    float3(scale, sc, "scale");
+    float3(shift, sh, "shift");
+    Launch L(v);
+    Tensor out = at::empty({v.size(0), f.size(1), 3, 3}, v.options());
+    check_status(sv3d_face_gather(v.data_ptr<float>(), f.data_ptr<int32_t>(), (int32_t)v.size(0), (int32_t)v.size(1),
+                                  (int32_t)f.size(1), (int32_t)f.size(0), sc, sh, out.data_ptr<float>(), L.stream),
+                 "sv3d_face_gather");
+    return out;
+}
+
+Tensor face_gather_meta(const Tensor &values, const Tensor &faces, FloatList, FloatList)
+{
+    return at::empty({values.size(0), faces.size(1), 3, 3}, values.options().dtype(at::kFloat));
+}
+
+Tensor face_scatter_gpu(const Tensor &grad_out, const Tensor &faces, int64_t num_vertices, FloatList scale)
+{
+    const Tensor g = f32c(grad_out), f = faces.contiguous();
+    float sc[3];
+    float3(scale, sc, "scale");
+    Launch L(g);
+    Tensor out = at::empty({g.size(0), num_vertices, 3}, g.options());
+    check_status(sv3d_face_scatter(g.data_ptr<float>(), f.data_ptr<int32_t>(), (int32_t)g.size(0),
+                                   (int32_t)num_vertices, (int32_t)g.size(1), (int32_t)f.size(0), sc,
+                                   out.data_ptr<float>(), L.stream),
+                 "sv3d_face_scatter");
+    return out;
+}
+
+Tensor face_scatter_meta(const Tensor &grad_out, const Tensor &, int64_t num_vertices, FloatList)
+{
+    return at::empty({grad_out.size(0), num_vertices, 3}, grad_out.options().dtype(at::kFloat));
+}
+
+Tensor face_gather_n_gpu(const Tensor &values, const Tensor &faces)
+{
+    TORCH_CHECK_VALUE(values.dim() == 3 && values.size(2) >= 1 && values.size(2) <= 8 && values.size(0) > 0,
+                      "values must be [B,V,C] with C <= 8, got ", values.sizes());
+    check_faces(values, faces);
+    const Tensor v = f32c(values), f = faces.contiguous();
+    Launch L(v);
+    Tensor out = at::empty({v.size(0), f.size(1), 3, v.size(2)}, v.options());
+    check_status(sv3d_face_gather_n(v.data_ptr<float>(), f.data_ptr<int32_t>(), (int32_t)v.size(0), (int32_t)v.size(1),
+                                    (int32_t)f.size(1), (int32_t)f.size(0), (int32_t)v.size(2), out.data_ptr<float>(),
+                                    L.stream),
+                 "sv3d_face_gather_n");
+    return out;
+}
+
+Tensor face_gather_n_meta(const Tensor &values, const Tensor &faces)
+{
+    return at::empty({values.size(0), faces.size(1), 3, values.size(2)}, values.options().dtype(at::kFloat));
+}
+
+Tensor face_scatter_n_gpu(const Tensor &grad_out, const Tensor &faces, int64_t num_vertices)
+{
+    const Tensor g = f32c(grad_out), f = faces.contiguous();
+    Launch L(g);
+    Tensor out = at::empty({g.size(0), num_vertices, g.size(3)}, g.options());
+    check_status(sv3d_face_scatter_n(g.data_ptr<float>(), f.data_ptr<int32_t>(), (int32_t)g.size(0),
+                                     (int32_t)num_vertices, (int32_t)g.size(1), (int32_t)f.size(0), (int32_t)g.size(3),
+                                     out.data_ptr<float>(), L.stream),
+                 "sv3d_face_scatter_n");
+    return out;
+}
+
+Tensor face_scatter_n_meta(const Tensor &grad_out, const Tensor &, int64_t num_vertices)
+{
+    return at::empty({grad_out.size(0), num_vertices, grad_out.size(3)}, grad_out.options().dtype(at::kFloat));
+}
+
+Tensor project_gather_gpu(const Tensor &vertices, const Tensor &cams, const Tensor &faces, FloatList mesh_cfg)
+{
+    check_mesh(vertices, cams, faces);
+    const Tensor v = f32c(vertices), c = f32c(cams), f = faces.contiguous();
+    const sv3d_mesh_input m = mesh_input(v, c, f, mesh_cfg, true);
+    Launch L(v);
+    Tensor out = at::empty({v.size(0), f.size(1), 3, 3}, v.options());
+    check_status(sv3d_project_gather(&m, (int32_t)v.size(0), (int32_t)f.size(1), out.data_ptr<float>(), L.stream),
+                 "sv3d_project_gather");
+    return out;
+}
+
+Tensor project_gather_meta(const Tensor &vertices, const Tensor &, const Tensor &faces, FloatList)
+{
+    return at::empty({vertices.size(0), faces.size(1), 3, 3}, vertices.options().dtype(at::kFloat));
+}
+
+std::tuple<Tensor, Tensor> project_scatter_gpu(const Tensor &grad_out, const Tensor &vertices, const Tensor &cams,
+                                               const Tensor &faces, FloatList mesh_cfg)
+{
+    const Tensor g = f32c(grad_out), v = f32c(vertices), c = f32c(cams), f = faces.contiguous();
+    const sv3d_mesh_input m = mesh_input(v, c, f, mesh_cfg, false);
+    Launch L(g);
+    Tensor gv = at::empty_like(v), gc = at::empty_like(c);
+    check_status(sv3d_project_scatter(&m, (int32_t)g.size(0), (int32_t)g.size(1), g.data_ptr<float>(),
+                                      gv.data_ptr<float>(), gc.data_ptr<float>(), L.stream),
+                 "sv3d_project_scatter");
+    return {gv, gc};
+}
+
+std::tuple<Tensor, Tensor> project_scatter_meta(const Tensor &grad_out, const Tensor &vertices, const Tensor &cams,
+                                                const Tensor &, FloatList)
+{
+    const auto opt = grad_out.options().dtype(at::kFloat);
+    return {at::empty(vertices.sizes(), opt), at::empty(cams.sizes(), opt)};
+}
+
+// ---- dispatcher handles (calls from the autograd kernels go below autograd) ----------------------
+template <class Sig>
+c10::TypedOperatorHandle<Sig> find_op(const char *name)
+{
+    return c10::Dispatcher::singleton().findSchemaOrThrow(name, "").typed<Sig>();
+}
+
+using RasterOut = std::tuple<Tensor, Tensor, Tensor>;
+
+RasterOut call_soft_rasterize(const Tensor &fv, const optional<Tensor> &tex, IntList icfg, FloatList fcfg)
+{
+    static auto op = find_op<RasterOut(const Tensor &, const optional<Tensor> &, IntList, FloatList)>("sv3d::soft_rasterize");
+    return op.call(fv, tex, icfg, fcfg);
+}
+
+std::tuple<Tensor, Tensor> call_soft_rasterize_backward(const Tensor &g, const optional<Tensor> &tex, const Tensor &rec,
+                                                        const Tensor &saved, IntList shape, IntList icfg,
+                                                        FloatList fcfg, bool need_tex)
+{
+    static auto op = find_op<std::tuple<Tensor, Tensor>(const Tensor &, const optional<Tensor> &, const Tensor &,
+                                                        const Tensor &, IntList, IntList, FloatList, bool)>(
+        "sv3d::soft_rasterize_backward");
+    return op.call(g, tex, rec, saved, shape, icfg, fcfg, need_tex);
+}
+
+RasterOut call_render(const Tensor &v, const Tensor &c, const Tensor &f, const optional<Tensor> &tex, FloatList mesh_cfg,
+                      IntList icfg, FloatList fcfg)
+{
+    static auto op = find_op<RasterOut(const Tensor &, const Tensor &, const Tensor &, const optional<Tensor> &,
+                                       FloatList, IntList, FloatList)>("sv3d::render");
+    return op.call(v, c, f, tex, mesh_cfg, icfg, fcfg);
+}
+
+RasterOut call_render_backward(const Tensor &g, const Tensor &v, const Tensor &c, const Tensor &f,
+                               const optional<Tensor> &tex, const Tensor &rec, const Tensor &saved, FloatList mesh_cfg,
+                               IntList icfg, FloatList fcfg, bool need_tex)
+{
+    static auto op = find_op<RasterOut(const Tensor &, const Tensor &, const Tensor &, const Tensor &,
+                                       const optional<Tensor> &, const Tensor &, const Tensor &, FloatList, IntList,
+                                       FloatList, bool)>("sv3d::render_backward");
+    return op.call(g, v, c, f, tex, rec, saved, mesh_cfg, icfg, fcfg, need_tex);
+}
+
+Tensor cast_like(const Tensor &g, at::ScalarType t) { return g.scalar_type() == t ? g : g.to(t); }
+
+// ---- autograd kernels -----------------------------------------------------------------------------
+struct SoftRasterizeFn : public torch::autograd::Function<SoftRasterizeFn> {
+    static variable_list forward(AutogradContext *ctx, const Tensor &fv, const optional<Tensor> &tex, IntList icfg,
+                                 FloatList fcfg)
+    {
+        at::AutoDispatchBelowADInplaceOrView guard;
+        auto out = call_soft_rasterize(fv, tex, icfg, fcfg);
+        const bool has_tex = tex.has_value() && tex->defined() && icfg[2] != SV3D_TEX_NONE;
+        ctx->save_for_backward({has_tex ? *tex : Tensor(), std::get<1>(out), std::get<2>(out)});
+        ctx->saved_data["icfg"] = icfg.vec();
+        ctx->saved_data["fcfg"] = fcfg.vec();
+        ctx->saved_data["shape"] = std::vector<int64_t>{fv.size(0), fv.size(1)};
+        ctx->saved_data["fv_dtype"] = (int64_t)fv.scalar_type();
+        ctx->saved_data["need_tex"] = has_tex && tex->requires_grad();
+        ctx->mark_non_differentiable({std::get<1>(out), std::get<2>(out)});
+        return {std::get<0>(out), std::get<1>(out), std::get<2>(out)};
+    }
+
+    static variable_list backward(AutogradContext *ctx, variable_list grads)
+    {
+        const auto saved = ctx->get_saved_variables();
+        const Tensor &tex = saved[0];
+        const auto icfg = ctx->saved_data["icfg"].toIntVector();
+        const auto fcfg = ctx->saved_data["fcfg"].toDoubleVector();
+        const auto shape = ctx->saved_data["shape"].toIntVector();
+        const bool need_tex = ctx->saved_data["need_tex"].toBool();
+        optional<Tensor> otex;
+        if (tex.defined()) otex = tex;
+        auto g = call_soft_rasterize_backward(grads[0], otex, saved[1], saved[2], shape, icfg, fcfg, need_tex);
+        Tensor gfv = cast_like(std::get<0>(g), (at::ScalarType)ctx->saved_data["fv_dtype"].toInt());
+        Tensor gtex = need_tex ? cast_like(std::get<1>(g), tex.scalar_type()) : Tensor();
+        return {gfv, gtex, Tensor(), Tensor()};
+    }
+};
+
+RasterOut soft_rasterize_autograd(const Tensor &fv, const optional<Tensor> &tex, IntList icfg, FloatList fcfg)
+{
+    auto out = SoftRasterizeFn::apply(fv, tex, icfg, fcfg);
+    return {out[0], out[1], out[2]};
+}
+
+struct RenderFn : public torch::autograd::Function<RenderFn> {
+    static variable_list forward(AutogradContext *ctx, const Tensor &v, const Tensor &c, const Tensor &f,
+                                 const optional<Tensor> &tex, FloatList mesh_cfg, IntList icfg, FloatList fcfg)
+    {
+        at::AutoDispatchBelowADInplaceOrView guard;
+        auto out = call_render(v, c, f, tex, mesh_cfg, icfg, fcfg);
+        const bool has_tex = tex.has_value() && tex->defined() && icfg[2] != SV3D_TEX_NONE;
+        ctx->save_for_backward({v, c, f, has_tex ? *tex : Tensor(), std::get<1>(out), std::get<2>(out)});
+        ctx->saved_data["mesh_cfg"] = mesh_cfg.vec();
+        ctx->saved_data["icfg"] = icfg.vec();
+        ctx->saved_data["fcfg"] = fcfg.vec();
+        ctx->saved_data["need_tex"] = has_tex && tex->requires_grad();
+        ctx->mark_non_differentiable({std::get<1>(out), std::get<2>(out)});
+        return {std::get<0>(out), std::get<1>(out), std::get<2>(out)};
+    }
+
+    static variable_list backward(AutogradContext *ctx, variable_list grads)
+    {
+        const auto saved = ctx->get_saved_variables();
+        const Tensor &v = saved[0], &c = saved[1], &f = saved[2], &tex = saved[3];
+        const auto mesh_cfg = ctx->saved_data["mesh_cfg"].toDoubleVector();
+        const auto icfg = ctx->saved_data["icfg"].toIntVector();
+        const auto fcfg = ctx->saved_data["fcfg"].toDoubleVector();
+        const bool need_tex = ctx->saved_data["need_tex"].toBool();
+        optional<Tensor> otex;
+        if (tex.defined()) otex = tex;
+        auto g = call_render_backward(grads[0], v, c, f, otex, saved[4], saved[5], mesh_cfg, icfg, fcfg, need_tex);
+        Tensor gtex = need_tex ? cast_like(std::get<2>(g), tex.scalar_type()) : Tensor();
+        return {cast_like(std::get<0>(g), v.scalar_type()), cast_like(std::get<1>(g), c.scalar_type()), Tensor(), gtex,
+                Tensor(), Tensor(), Tensor()};
+    }
+};
+
+RasterOut render_autograd(const Tensor &v, const Tensor &c, const Tensor &f, const optional<Tensor> &tex,
+                          FloatList mesh_cfg, IntList icfg, FloatList fcfg)
+{
+    auto out = RenderFn::apply(v, c, f, tex, mesh_cfg, icfg, fcfg);
+    return {out[0], out[1], out[2]};
+}
+
+struct ChamferFn : public torch::autograd::Function<ChamferFn> {
+    static variable_list forward(AutogradContext *ctx, const Tensor &a, const Tensor &b)
+    {
+        at::AutoDispatchBelowADInplaceOrView guard;
+        static auto op = find_op<std::tuple<Tensor, Tensor, Tensor, Tensor>(const Tensor &, const Tensor &)>("sv3d::chamfer_nn");
+        auto out = op.call(a, b);
+        ctx->save_for_backward({a, b, std::get<2>(out), std::get<3>(out)});
+        ctx->mark_non_differentiable({std::get<2>(out), std::get<3>(out)});
+        return {std::get<0>(out), std::get<1>(out), std::get<2>(out), std::get<3>(out)};
+    }
+
+    static variable_list backward(AutogradContext *ctx, variable_list grads)
+    {
+        const auto saved = ctx->get_saved_variables();
+        const Tensor &a = saved[0], &b = saved[1];
+        const bool need1 = ctx->needs_input_grad(0), need2 = ctx->needs_input_grad(1);
+        if (!need1 && !need2) return {Tensor(), Tensor()};
+        static auto op = find_op<std::tuple<Tensor, Tensor>(const Tensor &, const Tensor &, const optional<Tensor> &,
+                                                            const optional<Tensor> &, const Tensor &, const Tensor &,
+                                                            bool, bool)>("sv3d::chamfer_nn_backward");
+        optional<Tensor> g1, g2;
+        if (grads[0].defined()) g1 = grads[0];
+        if (grads[1].defined()) g2 = grads[1];
+        auto g = op.call(a, b, g1, g2, saved[2], saved[3], need1, need2);
+        return {need1 ? cast_like(std::get<0>(g), a.scalar_type()) : Tensor(),
+                need2 ? cast_like(std::get<1>(g), b.scalar_type()) : Tensor()};
+    }
+};
+
+std::tuple<Tensor, Tensor, Tensor, Tensor> chamfer_nn_autograd(const Tensor &a, const Tensor &b)
+{
+    auto out = ChamferFn::apply(a, b);
+    return {out[0], out[1], out[2], out[3]};
+}
+
+struct FaceGatherFn : public torch::autograd::Function<FaceGatherFn> {
+    static Tensor forward(AutogradContext *ctx, const Tensor &values, const Tensor &faces, FloatList scale,
+                          FloatList shift)
+    {
+        at::AutoDispatchBelowADInplaceOrView guard;
+        static auto op = find_op<Tensor(const Tensor &, const Tensor &, FloatList, FloatList)>("sv3d::face_gather");
+        ctx->save_for_backward({faces});
+        ctx->saved_data["scale"] = scale.vec();
+        ctx->saved_data["nv"] = values.size(1);
+        ctx->saved_data["dtype"] = (int64_t)values.scalar_type();
+        return op.call(values, faces, scale, shift);
+    }
+
+    static variable_list backward(AutogradContext *ctx, variable_list grads)
+    {
+        static auto op = find_op<Tensor(const Tensor &, const Tensor &, int64_t, FloatList)>("sv3d::face_scatter");
+        const auto saved = ctx->get_saved_variables();
+        const auto scale = ctx->saved_data["scale"].toDoubleVector();
+        Tensor g = op.call(grads[0], saved[0], ctx->saved_data["nv"].toInt(), scale);
+        return {cast_like(g, (at::ScalarType)ctx->saved_data["dtype"].toInt()), Tensor(), Tensor(), Tensor()};
+    }
+};
+
+Tensor face_gather_autograd(const Tensor &values, const Tensor &faces, FloatList scale, FloatList shift)
+{
+    return FaceGatherFn::apply(values, faces, scale, shift);
+}
+
+struct FaceGatherNFn : public torch::autograd::Function<FaceGatherNFn> {
+    static Tensor forward(AutogradContext *ctx, const Tensor &values, const Tensor &faces)
+    {
+        at::AutoDispatchBelowADInplaceOrView guard;
+        static auto op = find_op<Tensor(const Tensor &, const Tensor &)>("sv3d::face_gather_n");
+        ctx->save_for_backward({faces});
+        ctx->saved_data["nv"] = values.size(1);
+        ctx->saved_data["dtype"] = (int64_t)values.scalar_type();
+        return op.call(values, faces);
+    }
+
+    static variable_list backward(AutogradContext *ctx, variable_list grads)
+    {
+        static auto op = find_op<Tensor(const Tensor &, const Tensor &, int64_t)>("sv3d::face_scatter_n");
+        const auto saved = ctx->get_saved_variables();
+        Tensor g = op.call(grads[0], saved[0], ctx->saved_data["nv"].toInt());
+        return {cast_like(g, (at::ScalarType)ctx->saved_data["dtype"].toInt()), Tensor()};
+    }
+};
+
+Tensor face_gather_n_autograd(const Tensor &values, const Tensor &faces) { return FaceGatherNFn::apply(values, faces); }
+
+struct ProjectGatherFn : public torch::autograd::Function<ProjectGatherFn> {
+    static Tensor forward(AutogradContext *ctx, const Tensor &v, const Tensor &c, const Tensor &f, FloatList mesh_cfg)
+    {
+        at::AutoDispatchBelowADInplaceOrView guard;
+        static auto op = find_op<Tensor(const Tensor &, const Tensor &, const Tensor &, FloatList)>("sv3d::project_gather");
+        ctx->save_for_backward({v, c, f});
+        ctx->saved_data["mesh_cfg"] = mesh_cfg.vec();
+        return op.call(v, c, f, mesh_cfg);
+    }
+
+    static variable_list backward(AutogradContext *ctx, variable_list grads)
+    {
+        static auto op = find_op<std::tuple<Tensor, Tensor>(const Tensor &, const Tensor &, const Tensor &, const Tensor &,
+                                                            FloatList)>("sv3d::project_scatter");
+        const auto saved = ctx->get_saved_variables();
+        const auto mesh_cfg = ctx->saved_data["mesh_cfg"].toDoubleVector();
+        auto g = op.call(grads[0], saved[0], saved[1], saved[2], mesh_cfg);
+        return {cast_like(std::get<0>(g), saved[0].scalar_type()), cast_like(std::get<1>(g), saved[1].scalar_type()),
+                Tensor(), Tensor()};
+    }
+};
+
+Tensor project_gather_autograd(const Tensor &v, const Tensor &c, const Tensor &f, FloatList mesh_cfg)
+{
+    return ProjectGatherFn::apply(v, c, f, mesh_cfg);
+}
+
+}  // namespace
+
+TORCH_LIBRARY(sv3d, m)
+{
+    m.def("soft_rasterize(Tensor face_vertices, Tensor? textures, int[] icfg, float[] fcfg) -> (Tensor, Tensor, Tensor)");
+    m.def("soft_rasterize_backward(Tensor grad_rgba, Tensor? textures, Tensor face_rec, Tensor pixel_saved, "
+          "int[] shape, int[] icfg, float[] fcfg, bool need_textures) -> (Tensor, Tensor)");
+    m.def("render(Tensor vertices, Tensor cams, Tensor faces, Tensor? textures, float[] mesh_cfg, int[] icfg, "
+          "float[] fcfg) -> (Tensor, Tensor, Tensor)");
+    m.def("render_backward(Tensor grad_rgba, Tensor vertices, Tensor cams, Tensor faces, Tensor? textures, "
+          "Tensor face_rec, Tensor pixel_saved, float[] mesh_cfg, int[] icfg, float[] fcfg, bool need_textures) "
+          "-> (Tensor, Tensor, Tensor)");
+    m.def("chamfer_nn(Tensor xyz1, Tensor xyz2) -> (Tensor, Tensor, Tensor, Tensor)");
+    m.def("chamfer_nn_backward(Tensor xyz1, Tensor xyz2, Tensor? grad_dist1, Tensor? grad_dist2, Tensor idx1, "
+          "Tensor idx2, bool need1, bool need2) -> (Tensor, Tensor)");
+    m.def("face_gather(Tensor values, Tensor faces, float[] scale, float[] shift) -> Tensor");
+    m.def("face_scatter(Tensor grad_out, Tensor faces, int num_vertices, float[] scale) -> Tensor");
+    m.def("face_gather_n(Tensor values, Tensor faces) -> Tensor");
+    m.def("face_scatter_n(Tensor grad_out, Tensor faces, int num_vertices) -> Tensor");
+    m.def("project_gather(Tensor vertices, Tensor cams, Tensor faces, float[] mesh_cfg) -> Tensor");
+    m.def("project_scatter(Tensor grad_out, Tensor vertices, Tensor cams, Tensor faces, float[] mesh_cfg) -> (Tensor, Tensor)");
+}
+
+TORCH_LIBRARY_IMPL(sv3d, CUDA, m)
+{
+    m.impl("soft_rasterize", soft_rasterize_gpu);
+    m.impl("soft_rasterize_backward", soft_rasterize_backward_gpu);
+    m.impl("render", render_gpu);
+    m.impl("render_backward", render_backward_gpu);
+    m.impl("chamfer_nn", chamfer_nn_gpu);
+    m.impl("chamfer_nn_backward", chamfer_nn_backward_gpu);
+    m.impl("face_gather", face_gather_gpu);
+    m.impl("face_scatter", face_scatter_gpu);
+    m.impl("face_gather_n", face_gather_n_gpu);
+    m.impl("face_scatter_n", face_scatter_n_gpu);
+    m.impl("project_gather", project_gather_gpu);
+    m.impl("project_scatter", project_scatter_gpu);
+}
+
+TORCH_LIBRARY_IMPL(sv3d, Meta, m)
+{
+    m.impl("soft_rasterize", soft_rasterize_meta);
+    m.impl("soft_rasterize_backward", soft_rasterize_backward_meta);
+    m.impl("render", render_meta);
+    m.impl("render_backward", render_backward_meta);
+    m.impl("chamfer_nn", chamfer_nn_meta);
+    m.impl("chamfer_nn_backward", chamfer_nn_backward_meta);
+    m.impl("face_gather", face_gather_meta);
+    m.impl("face_scatter", face_scatter_meta);
+    m.impl("face_gather_n", face_gather_n_meta);
+    m.impl("face_scatter_n", face_scatter_n_meta);
+    m.impl("project_gather", project_gather_meta);
+    m.impl("project_scatter", project_scatter_meta);
+}
+
+TORCH_LIBRARY_IMPL(sv3d, Autograd, m)
+{
+    m.impl("soft_rasterize", soft_rasterize_autograd);
+    m.impl("render", render_autograd);
+    m.impl("chamfer_nn", chamfer_nn_autograd);
+    m.impl("face_gather", face_gather_autograd);
+    m.impl("face_gather_n", face_gather_n_autograd);
+    m.impl("project_gather", project_gather_autograd);
+}

@@ -230,3 +230,25 @@ def test_ops_refuse_cpu_tensors():
         sv3d.chamfer_nn(torch.zeros(1, 4, 3), torch.zeros(1, 4, 3))
     with pytest.raises(NotImplementedError):
         sv3d.soft_rasterize(torch.zeros(1, 4, 3, 3), None, 16)
+
+
+def test_torch_operator_library_registers_every_operator():
+    """libsv3d_torch.so loads next to libsv3d_hip.so and defines the sv3d::* operators with Meta
+    kernels (shapes without a GPU); CPU tensors are refused by the dispatcher, not computed."""
+    import torch
+    import sv3d  # noqa: F401  (loads both libraries)
+    names = ("soft_rasterize", "soft_rasterize_backward", "render", "render_backward", "chamfer_nn",
+             "chamfer_nn_backward", "face_gather", "face_scatter", "face_gather_n", "face_scatter_n",
+             "project_gather", "project_scatter")
+    for n in names:
+        assert hasattr(torch.ops.sv3d, n), n
+    meta = dict(device="meta")
+    v, cams = torch.empty(3, 642, 3, **meta), torch.empty(3, 7, **meta)
+    f = torch.empty(1, 1280, 3, dtype=torch.int32, **meta)
+    rgba, rec, saved = torch.ops.sv3d.render(v, cams, f, None, [5.0, 1, -1, 1, 0, 0, 2.732], [512, 2, 0, 1, 1, 0],
+                                             [0, 0, 0, 1, 100, 1e-3, 1e-5, 1e-10, 1e-4])
+    assert rgba.shape == (3, 4, 256, 256) and saved.numel() == 3 * 512 * 512
+    d1, d2, i1, i2 = torch.ops.sv3d.chamfer_nn(torch.empty(2, 10, 3, **meta), torch.empty(2, 20, 3, **meta))
+    assert d2.shape == (2, 20) and i1.dtype == torch.int32
+    with pytest.raises(NotImplementedError):
+        torch.ops.sv3d.chamfer_nn(torch.zeros(1, 3, 3), torch.zeros(1, 4, 3))

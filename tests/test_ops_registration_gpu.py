@@ -16,32 +16,50 @@ def _mesh(B=2):
     return random_vertices(verts, B, 0).cuda(), random_cams(B, 1).cuda(), faces[None].cuda().contiguous()
 
 
+MESH_CFG = [5.0, 1.0, -1.0, 1.0, 0.0, 0.0, 2.732]        # offset_z, scale, shift
+FCFG = [0.0, 0.0, 0.0, 1.0, 100.0, 1e-3, 1e-4, 1e-10, 1e-2]   # background, near, far, eps, sigma, dist_eps, gamma
+
+
 def test_opcheck_raster_and_render_ops():
     from sv3d import ops
     v, cams, f = _mesh()
     fv = ops.project_gather(v, cams, f, 5.0, (1.0, -1.0, 1.0), (0.0, 0.0, 2.732))
     tex = torch.rand(2, f.shape[1], 4, 3, device="cuda")
-    scal = (32, 1, 1, 2, True, [0.0, 0.0, 0.0], 1.0, 100.0, 1e-3, 1e-4, 1e-10, 1e-2)
-    torch.library.opcheck(ops.soft_rasterize_op, (fv.requires_grad_(True), tex.requires_grad_(True)) + scal,
+    surface = [32, 1, 1, 2, 1, 0]                        # raster_size, aa, mode, res, double_side, alpha_only
+    sv = torch.ops.sv3d
+    torch.library.opcheck(sv.soft_rasterize.default, (fv.requires_grad_(True), tex.requires_grad_(True), surface, FCFG),
                           test_utils=TESTS)
-    torch.library.opcheck(ops.soft_rasterize_op, (fv, None, 32, 1, 0, 1, True, [0.0, 0.0, 0.0], 1.0, 100.0,
-                                                  1e-3, 1e-4, 1e-10, 1e-2), test_utils=TESTS)
-    torch.library.opcheck(ops.render_op, (v.requires_grad_(True), cams.requires_grad_(True), f, tex, 5.0,
-                                          [1.0, -1.0, 1.0], [0.0, 0.0, 2.732]) + scal, test_utils=TESTS)
+    torch.library.opcheck(sv.soft_rasterize.default, (fv, None, [32, 1, 0, 1, 1, 0], FCFG), test_utils=TESTS)
+    torch.library.opcheck(sv.soft_rasterize.default, (fv, None, [32, 2, 0, 1, 1, 1], FCFG), test_utils=TESTS)
+    torch.library.opcheck(sv.render.default, (v.requires_grad_(True), cams.requires_grad_(True), f, tex, MESH_CFG,
+                                              surface, FCFG), test_utils=TESTS)
 
 
 def test_opcheck_mesh_and_chamfer_ops():
-    from sv3d import ops
     v, cams, f = _mesh()
-    torch.library.opcheck(ops.face_gather_op, (v.requires_grad_(True), f, [1.0, -1.0, 1.0], [0.0, 0.0, 1.0]),
+    sv = torch.ops.sv3d
+    torch.library.opcheck(sv.face_gather.default, (v.requires_grad_(True), f, [1.0, -1.0, 1.0], [0.0, 0.0, 1.0]),
                           test_utils=TESTS)
-    torch.library.opcheck(ops.project_gather_op, (v, cams.requires_grad_(True), f, 5.0, [1.0, -1.0, 1.0],
-                                                  [0.0, 0.0, 2.732]), test_utils=TESTS)
+    torch.library.opcheck(sv.project_gather.default, (v, cams.requires_grad_(True), f, MESH_CFG), test_utils=TESTS)
     parts = torch.rand(2, v.shape[1], 8, device="cuda", requires_grad=True)
-    torch.library.opcheck(ops.face_gather_n_op, (parts, f), test_utils=TESTS)
+    torch.library.opcheck(sv.face_gather_n.default, (parts, f), test_utils=TESTS)
     a = torch.randn(2, 50, 3, device="cuda", requires_grad=True)
     b = torch.randn(2, 70, 3, device="cuda", requires_grad=True)
-    torch.library.opcheck(ops.chamfer_nn_op, (a, b), test_utils=TESTS)
+    torch.library.opcheck(sv.chamfer_nn.default, (a, b), test_utils=TESTS)
+
+
+def test_half_precision_inputs_compute_in_fp32_and_return_their_own_type():
+    """Under autocast the trainer hands fp16 tensors to the renderer (train_utils.py:192): the
+    kernels compute in fp32 and gradients come back in the inputs' types."""
+    import sv3d
+    v, cams, f = _mesh()
+    vh = v.half().requires_grad_(True)
+    out = sv3d.render(vh, cams, f, None, 32, offset_z=5.0, alpha_only=True)
+    assert out.dtype == torch.float32
+    out.sum().backward()
+    assert vh.grad.dtype == torch.float16 and torch.isfinite(vh.grad).all()
+    ref = sv3d.render(vh.detach().float(), cams, f, None, 32, offset_z=5.0, alpha_only=True)
+    assert torch.equal(out.detach(), ref)
 
 
 def test_ops_trace_with_fake_tensors():
