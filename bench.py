@@ -13,8 +13,22 @@ weak and `value` is the sum over ranks.
 
 Prints ONE JSON line (rank 0).  `roofline` is for the kernel with the longest average
 launch (FP32 VALU bound; timed with HIP events recorded on the launch stream around that
-kernel on every 10th timed step).  `cpu_baseline` is the dense fp32 torch evaluation of the same
-formulas (oracle port) on the host cores, on a bounded sample.
+kernel on every 10th timed step, every 4th of runs shorter than 100 steps).  `cpu_baseline`
+is the dense fp32 torch evaluation of the same formulas (oracle port) on the host cores, on a
+bounded sample, with the other legs of the CPU reference configuration (network forward on one
+256x256 image, dense Chamfer 642 x 642, dense Laplacian) beside it.
+
+Three more objects ride on the same line; they run BEFORE the headline's timed region (their
+own timings, their own warm-up), so the headline starts on a GPU that is already busy:
+  `api`         the same batch through the Python API (`sv3d.render`: camera stage + rasterizer,
+                forward + backward to vertices and cameras), and one `SoftNeuralRenderer` call at
+                the reference's own constants (anti-aliased 512^2 raster, sigma 1e-5)
+  `chamfer`     `sv3d_chamfer_forward` at 64 x 642^2, 64 x 2048^2 and 16 x 8192^2: TFLOP/s and
+                fraction of the FP32 vector peak (16 B N M flop per call)
+  `train_step`  the synthetic CMR-style training step of examples/cmr_synthetic.py at the
+                reference's default batch (4 dataset images -> 64 rendered images per pass):
+                dataset images/s per rank and summed; with N > 1 the step runs under
+                DistributedDataParallel, so its gradients are all-reduced by RCCL
 """
 import argparse
 import ctypes
@@ -47,7 +61,9 @@ def parse():
     ap.add_argument("--tex-size", type=int, default=6)
     ap.add_argument("--anti-aliasing", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--cpu-seconds", type=float, default=3.0, help="budget of the dense silhouette leg")
+    ap.add_argument("--no-extras", action="store_true", help="headline only: no api / chamfer / train_step legs")
+    ap.add_argument("--train-steps", type=int, default=12, help="timed steps of the train_step leg")
     return ap.parse_args()
 
 
@@ -134,10 +150,196 @@ def cpu_baseline(args, fv0, seconds):
             break
     dt = time.perf_counter() - t0
     img_per_s = (done_px / float(S * S)) / dt
-    return {"value": img_per_s, "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": "dense fp32 torch-CPU silhouette fwd+bwd (all pixels x all %d faces, oracle "
-                      "port) on %d of %d pixel rows of image 0, %.1f s, scaled to a full image"
-                      % (fv.shape[0], done_px // S, S, dt)}
+    out = {"value": img_per_s, "unit": "images/s", "cores": cores, "kind": "port",
+           "sample": "dense fp32 torch-CPU silhouette fwd+bwd (all pixels x all %d faces, oracle "
+                     "port) on %d of %d pixel rows of image 0, %.1f s, scaled to a full image"
+                     % (fv.shape[0], done_px // S, S, dt)}
+    out.update(cpu_reference_legs(args, 1.0 / img_per_s))
+    return out
+
+
+def _median_ms(fn, repeats=5, warm=1):
+    for _ in range(warm):
+        fn()
+    ts = []
+    for _ in range(repeats):
+        t0 = time.perf_counter()
+        fn()
+        ts.append(time.perf_counter() - t0)
+    return 1e3 * sorted(ts)[len(ts) // 2]
+
+
+def cpu_reference_legs(args, silhouette_s):
+    """The other legs of the CPU reference configuration (one synthetic 256x256 image, 642 vertices /
+    1280 faces), each timed on the host cores with dense torch: the network forward (ResNet-18-shaped
+    encoder + shape / camera / texture heads of examples/cmr_synthetic.py, random weights, inference
+    mode), Chamfer 642 x 642 forward + backward, the uniform Laplacian loss forward + backward
+    (dense V x V operator, as the upstream module holds it)."""
+    from oracle import meshreg_oracle
+    from sv3d import meshgen
+    cmr = _load_cmr_module()
+    verts, faces = meshgen.icosphere(3)
+    vt, ft = torch.from_numpy(verts), torch.from_numpy(faces).long()
+    net = cmr.MeshNetLite(vt, ft, 8, 6).eval()
+    img = torch.rand(1, 3, 256, 256, generator=torch.Generator().manual_seed(0))
+
+    def net_forward():
+        with torch.no_grad():
+            net(img)
+
+    a = (vt[None] + 0.02 * torch.randn(1, vt.shape[0], 3, generator=torch.Generator().manual_seed(1)))
+    b = (a * torch.tensor([-1.0, 1.0, 1.0])).clone().requires_grad_(True)
+
+    def chamfer():
+        d = ((a[:, :, None] - b[:, None]) ** 2).sum(-1)            # dense [1,N,M] squared distances
+        d.min(1).values.mean().backward()                            # dist2.mean(), loss_utils.py:87-88
+
+    x = a.clone().requires_grad_(True)
+
+    def laplacian():
+        meshreg_oracle.laplacian_loss(x, faces).sum().backward()
+
+    net_ms, ch_ms, lap_ms = _median_ms(net_forward, 3), _median_ms(chamfer), _median_ms(laplacian)
+    return {"reference_config": {
+        "what": "CPU reference configuration: network forward on one 256x256 image + dense silhouette "
+                "fwd+bwd + Chamfer 642x642 fwd+bwd + dense Laplacian fwd+bwd, torch on the host cores",
+        "network_forward_ms": net_ms, "silhouette_fwd_bwd_ms": 1e3 * silhouette_s,
+        "chamfer_642_fwd_bwd_ms": ch_ms, "laplacian_fwd_bwd_ms": lap_ms,
+        "total_ms": net_ms + 1e3 * silhouette_s + ch_ms + lap_ms}}
+
+
+def _load_cmr_module():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("cmr_synthetic", os.path.join(ROOT, "examples", "cmr_synthetic.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def api_leg(args, device, rank):
+    """The headline batch through the Python API, and one SoftNeuralRenderer call at the reference's
+    constants; images/s of forward + backward (gradients to vertices and cameras)."""
+    import sv3d
+    from nnutils.softras import SoftNeuralRenderer
+    from sv3d import meshgen
+    verts, faces = meshgen.icosphere(args.subdivide)
+    g = torch.Generator().manual_seed(2000 + rank)
+    B, H = args.batch, args.image_size
+    v = (torch.from_numpy(verts)[None] + 0.02 * torch.randn(B, verts.shape[0], 3, generator=g)).to(device)
+    cams = torch.empty(B, 7)
+    cams[:, 0] = 0.6 + 0.3 * torch.rand(B, generator=g)
+    cams[:, 1:3] = 0.2 * torch.rand(B, 2, generator=g) - 0.1
+    q = torch.randn(B, 4, generator=g)
+    cams[:, 3:] = q / q.norm(dim=1, keepdim=True)
+    cams = cams.to(device)
+    f = torch.from_numpy(faces)[None].to(device).to(torch.int32).contiguous()
+    grad = (2 * torch.rand(B, H, H, generator=g) - 1).to(device)
+    vg, cg = v.requires_grad_(True), cams.requires_grad_(True)
+    renderer = SoftNeuralRenderer(H)
+    f_all = f.expand(B, -1, -1).contiguous()
+
+    def headline_config():
+        out = sv3d.render(vg, cg, f, None, H, offset_z=5.0, scale=(1.0, -1.0, 1.0), shift=(0.0, 0.0, 2.732),
+                          anti_aliasing=args.anti_aliasing, sigma_val=args.sigma, alpha_only=True)
+        out.backward(grad)
+
+    def reference_defaults():
+        renderer(vg, f_all, cg).backward(grad)
+
+    res = {}
+    for name, fn in (("headline_config", headline_config), ("reference_defaults", reference_defaults)):
+        for _ in range(30):
+            fn()
+        torch.cuda.synchronize()
+        gc.collect()
+        gc.disable()
+        n = 300
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        gc.enable()
+        res[name] = {"us_per_call": 1e6 * dt / n, "images_per_s": B * n / dt}
+    res["what"] = ("forward + backward of one renderer call on the headline batch through the Python API: "
+                   "headline_config = sv3d.render (camera stage + rasterizer at the headline's sigma and raster), "
+                   "reference_defaults = nnutils.softras.SoftNeuralRenderer(img_size)(vertices, faces, cams) "
+                   "(anti-aliased 2x raster, sigma 1e-5)")
+    return res
+
+
+def chamfer_leg(device):
+    """sv3d_chamfer_forward at the reference's size and the two sizes the configurations name."""
+    from sv3d import _lib as L, workmodel
+    lib = L.lib()
+    vp = lambda t: ctypes.c_void_p(t.data_ptr())
+    stream = ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+    rows = []
+    for B, N in ((4, 642), (64, 642), (64, 2048), (16, 8192)):
+        g = torch.Generator().manual_seed(5)
+        a, b = torch.randn(B, N, 3, generator=g).to(device), torch.randn(B, N, 3, generator=g).to(device)
+        d1, d2 = torch.empty(B, N, device=device), torch.empty(B, N, device=device)
+        i1 = torch.empty(B, N, dtype=torch.int32, device=device)
+        i2 = torch.empty(B, N, dtype=torch.int32, device=device)
+
+        def fwd():
+            L.check(lib.sv3d_chamfer_forward(vp(a), vp(b), B, N, N, vp(d1), vp(d2), vp(i1), vp(i2), stream), "chamfer")
+
+        for _ in range(5):
+            fwd()
+        iters = 50
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fwd()
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) / iters * 1e3
+        tf = workmodel.chamfer_flops(B, N, N) / us / 1e6
+        rows.append({"clouds": B, "points": N, "forward_us": us, "tflops": tf,
+                     "frac_of_fp32_valu_peak": tf / workmodel.FP32_VALU_PEAK_TFLOPS})
+    return rows
+
+
+def train_step_leg(args, device, world, rank):
+    """examples/cmr_synthetic.py's step (encoder, camera hypotheses, shared render passes, part maps,
+    Chamfer, regularisers, distance-map loss, autocast + clip + Adam x2) at batch 4 per rank."""
+    import tempfile
+    cmr = _load_cmr_module()
+    tmp = tempfile.mkdtemp(prefix="sv3d_bench_")
+    o = cmr.parse(["--batch_size", "4", "--seg_train", "1", "--print_scalars", "0", "--checkpoint_dir", tmp,
+                   "--name", "bench", "--dataset_size", "1024", "--save_latest_freq", "1000000"])
+    o.epoch_fraction = 1.0
+    from nnutils import train_utils
+    env = train_utils.init_distributed(gpu_id=device.index)
+    t = cmr.ShapeTrainer(o, env)
+    t.init_training()
+    o.num_iter = 6                                   # warm-up: library start-up, autotuning, allocator
+    t.train()
+    o.num_iter = args.train_steps
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    steps = t.train()
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=device)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        dt = float(tt.item())
+    per_rank = steps * o.batch_size / dt
+    return {"what": "synthetic CMR-style training step (examples/cmr_synthetic.py): ResNet-18-shaped encoder under "
+                    "autocast, 8 camera hypotheses x (4 + 4 mirrored) images = 64 rendered images per pass, RGB + "
+                    "silhouette + 8 part maps from 2 shared passes, Chamfer, Laplacian + flatten, distance-map "
+                    "loss, clip + Adam x2; LPIPS replaced by L1 (weights absent)",
+            "batch_per_rank": o.batch_size, "rendered_images_per_pass": 16 * o.batch_size, "steps": steps,
+            "ms_per_step": 1e3 * dt / steps, "dataset_images_per_s_per_rank": per_rank,
+            "dataset_images_per_s": per_rank * world, "ranks": world,
+            "gradient_all_reduce": ("RCCL via DistributedDataParallel over %d ranks"
+                                    % torch.distributed.get_world_size()) if world > 1 else "none (one rank)"}
 
 
 def pmc_traffic(args, kernel):
@@ -197,7 +399,8 @@ def main():
     # Kernel durations come from HIP events recorded on the kernels' stream inside the timed
     # region.  An event pair costs a few microseconds of stream time, a fifth of this step, so
     # only every `stride`-th step carries them; the other steps use the plain entry points.
-    stride = max(1, args.event_stride)
+    # (short runs: every 4th step, so that a 20-step run still rests on five samples)
+    stride = max(1, args.event_stride) if K >= 100 else min(4, max(1, args.event_stride))
     timed_steps = [i for i in range(K) if i % stride == 0]
     fe = ev.create(2 * len(timed_steps))
     be = ev.create(2 * len(timed_steps))
@@ -224,6 +427,15 @@ def main():
         if world > 1:
             import torch.distributed as dist
             dist.barrier()
+
+    extras = {}
+    if not args.no_extras:
+        # own warm-up and timing each; they also leave the GPU busy before the headline starts
+        extras["api"] = api_leg(args, device, rank)
+        extras["chamfer"] = chamfer_leg(device)
+        extras["train_step"] = train_step_leg(args, device, world, rank)
+        gc.collect()
+        torch.cuda.empty_cache()
 
     for _ in range(W):
         step()
@@ -289,6 +501,7 @@ def main():
                    "parallelism": "image-sharded x%d" % world},
         "roofline": roofline,
     }
+    out.update(extras)
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args, fv[0], args.cpu_seconds)
     print(json.dumps(out), flush=True)

@@ -42,11 +42,12 @@ void check_status(int st, const char *what)
     TORCH_CHECK(st == SV3D_OK, what, " failed: ", sv3d_strerror(st), " (status ", st, ")");
 }
 
+// fp32 contiguous form of a tensor: the tensor itself when it already is that (these kernels run
+// below autograd, nothing they do is recorded), a converted copy otherwise
 Tensor f32c(const Tensor &t)
 {
-    Tensor r = t.detach();
-    if (r.scalar_type() != at::kFloat) r = r.to(at::kFloat);
-    return r.contiguous();
+    if (t.scalar_type() == at::kFloat && t.is_contiguous()) return t;
+    return t.to(at::kFloat).contiguous();
 }
 
 struct Launch {

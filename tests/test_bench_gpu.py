@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 @pytest.mark.gpu
 def test_bench_prints_one_json_line_with_roofline_and_cpu_baseline():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "40", "--warmup", "10",
-                          "--cpu-seconds", "2"], capture_output=True, text=True, timeout=110, cwd=ROOT)
+                          "--cpu-seconds", "2", "--train-steps", "4"], capture_output=True, text=True, timeout=280, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.strip()]
     assert len(lines) == 1, lines
@@ -30,3 +30,9 @@ def test_bench_prints_one_json_line_with_roofline_and_cpu_baseline():
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0 < r["frac"] < 1
     c = j["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
+    legs = c["reference_config"]
+    assert legs["total_ms"] > legs["silhouette_fwd_bwd_ms"] > 0 and legs["network_forward_ms"] > 0
+    assert j["api"]["headline_config"]["images_per_s"] > 1e4 and j["api"]["reference_defaults"]["images_per_s"] > 1e4
+    assert [r["points"] for r in j["chamfer"]] == [642, 642, 2048, 8192] and all(r["tflops"] > 0 for r in j["chamfer"])
+    t = j["train_step"]
+    assert t["ranks"] == 1 and t["steps"] == 4 and t["dataset_images_per_s"] > 10

@@ -11,5 +11,5 @@ timeout -k 10 120 python -u -c "import __graft_entry__ as g; g.smoke()" > gpurun
 tail -1 gpurun_out/smoke.log
 timeout -k 10 300 python -u bench.py > gpurun_out/bench.json 2> gpurun_out/bench.err || { tail -20 gpurun_out/bench.err; exit 1; }
 cat gpurun_out/bench.json
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -o r1 -- python bench.py --no-cpu-baseline > gpurun_out/prof_bench.json 2> gpurun_out/prof.err || { tail -20 gpurun_out/prof.err; exit 1; }
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -o r1 -- python bench.py --no-cpu-baseline --no-extras > gpurun_out/prof_bench.json 2> gpurun_out/prof.err || { tail -20 gpurun_out/prof.err; exit 1; }
 find gpurun_out/prof -name "*stats*" | head; f=$(find gpurun_out/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cat "$f"
