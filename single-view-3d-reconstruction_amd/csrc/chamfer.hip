@@ -5,12 +5,13 @@
 // cloud and the (lowest) index where it is attained.  FP32 VALU bound: 8 FLOP per
 // (query, candidate) pair on 12 bytes per point.
 //
-// Layout of one workgroup (256 threads = 4 waves):
-//   * 64*Q query points live in registers, Q per lane, the SAME queries in all 4 waves;
+// Layout of one workgroup (W waves; 4, or 16 for calls so small that they leave most CUs idle and
+// a wave's scan length is the whole run time):
+//   * 64*Q query points live in registers, Q per lane, the SAME queries in all W waves;
 //   * candidate points are staged through LDS in tiles of TILE points padded to
 //     float4, so one broadcast ds_read_b128 feeds Q distance evaluations;
-//   * wave w scans quarter w of every tile, so each wave sees its candidates in
-//     increasing index order and a strict `<` keeps the lowest index; the four
+//   * wave w scans share w of every tile, so each wave sees its candidates in
+//     increasing index order and a strict `<` keeps the lowest index; the W
 //     per-wave results are merged through LDS by (distance, index) lexicographic
 //     order, which is the global "lowest index among the minima".
 #include <hip/hip_runtime.h>
@@ -23,12 +24,11 @@
 namespace {
 
 constexpr int kThreads = 256;
-constexpr int kWaves = 4;
 constexpr int kTile = 1024;          // candidates staged per LDS tile (16 KiB)
 constexpr int kGroup = 8;            // candidates per group minimum
 
-template <int Q>
-__global__ __launch_bounds__(kThreads) void chamfer_nn_kernel(
+template <int Q, int kWaves>
+__global__ __launch_bounds__(64 * kWaves) void chamfer_nn_kernel(
     const float *__restrict__ xyz1, const float *__restrict__ xyz2, int N, int M,
     float *__restrict__ dist1, float *__restrict__ dist2,
     int32_t *__restrict__ idx1, int32_t *__restrict__ idx2, int blocks_dir0)
@@ -67,7 +67,7 @@ __global__ __launch_bounds__(kThreads) void chamfer_nn_kernel(
     for (int t0 = 0; t0 < nc; t0 += kTile) {
         const int tn = min(kTile, nc - t0);
         __syncthreads();
-        for (int j = threadIdx.x; j < tn; j += kThreads) {
+        for (int j = threadIdx.x; j < tn; j += 64 * kWaves) {
             const float *c = cp + 3 * (size_t)(t0 + j);
             s_pts[j] = make_float4(c[0], c[1], c[2], 0.f);
         }
@@ -138,7 +138,7 @@ __global__ __launch_bounds__(kThreads) void chamfer_nn_kernel(
         s_bidx[wave][k * 64 + lane] = bi[k];
     }
     __syncthreads();
-    for (int s = threadIdx.x; s < 64 * Q; s += kThreads) {
+    for (int s = threadIdx.x; s < 64 * Q; s += 64 * kWaves) {
         float bd = s_best[0][s];
         int bj = s_bidx[0][s];
 #pragma unroll
@@ -309,12 +309,17 @@ extern "C" int sv3d_chamfer_forward(const float *xyz1, const float *xyz2, int32_
     const int per = 64 * Q;
     const int b0 = (N + per - 1) / per, b1 = (M + per - 1) / per;
     dim3 grid(b0 + b1, B), block(kThreads);
+    // at most a workgroup per CU: sixteen waves split every tile, so that the scan of a wave -- the
+    // whole run time of such a call -- is a quarter as long (4 x 642 points: 8.4 -> about 6 us)
+    const bool tiny = (long)(b0 + b1) * B <= 256;
     if (Q == 4)
-        hipLaunchKernelGGL(chamfer_nn_kernel<4>, grid, block, 0, s, xyz1, xyz2, N, M, dist1, dist2, idx1, idx2, b0);
+        hipLaunchKernelGGL((chamfer_nn_kernel<4, 4>), grid, block, 0, s, xyz1, xyz2, N, M, dist1, dist2, idx1, idx2, b0);
     else if (Q == 2)
-        hipLaunchKernelGGL(chamfer_nn_kernel<2>, grid, block, 0, s, xyz1, xyz2, N, M, dist1, dist2, idx1, idx2, b0);
+        hipLaunchKernelGGL((chamfer_nn_kernel<2, 4>), grid, block, 0, s, xyz1, xyz2, N, M, dist1, dist2, idx1, idx2, b0);
+    else if (tiny)
+        hipLaunchKernelGGL((chamfer_nn_kernel<1, 16>), grid, dim3(1024), 0, s, xyz1, xyz2, N, M, dist1, dist2, idx1, idx2, b0);
     else
-        hipLaunchKernelGGL(chamfer_nn_kernel<1>, grid, block, 0, s, xyz1, xyz2, N, M, dist1, dist2, idx1, idx2, b0);
+        hipLaunchKernelGGL((chamfer_nn_kernel<1, 4>), grid, block, 0, s, xyz1, xyz2, N, M, dist1, dist2, idx1, idx2, b0);
     return launch_status();
 }
 
