@@ -78,14 +78,23 @@ def surface_light(face_vertices, ambient, directional, direction=(0.0, 1.0, 0.0)
 def render(vertices, faces, cams, textures=None, *, img_size=256, texture_type="surface",
            anti_aliasing=True, sigma=1e-5, gamma=1e-4, dist_eps=1e-10,
            ambient=0.8, directional=0.5, light_dir=(0.0, 1.0, 0.0), background=(0.0, 0.0, 0.0),
-           offset_z=5.0):
-    """softras.py:57-77.  Returns mask [B,H,W] when textures is None else RGB [B,3,H,W]."""
+           offset_z=5.0, stage_dtype=None):
+    """softras.py:57-77.  Returns mask [B,H,W] when textures is None else RGB [B,3,H,W].
+
+    `stage_dtype` (e.g. torch.float32): the camera stage -- projection, flip, look_at shift -- is
+    evaluated in that type and its result handed to the rasterizer in the inputs' type.  With fp64
+    inputs this isolates what storing the projected vertices in single precision costs, the floor
+    under any fp32 implementation of the call, whatever its rasterizer does."""
+    dt = vertices.dtype
+    if stage_dtype is not None:
+        vertices, cams = vertices.to(stage_dtype), cams.to(stage_dtype)
     verts = orthographic_proj_withz(vertices, cams, offset_z=offset_z)          # :58
     vs = verts * torch.tensor([1.0, -1.0, 1.0], dtype=verts.dtype)                # :59-60
     S = img_size * (2 if anti_aliasing else 1)
     fv_world = face_gather(vs, faces)
     shift = torch.tensor([0.0, 0.0, -EYE_Z], dtype=verts.dtype)
-    fv = fv_world + shift                                                         # look_at, orthogonal
+    fv = (fv_world + shift).to(dt)                                                # look_at, orthogonal
+    fv_world = fv_world.to(dt)
     kw = dict(sigma=sigma, gamma=gamma, dist_eps=dist_eps, background=background)
     if textures is None:                                                          # :62-65
         rgba, _ = raster_oracle.soft_rasterize(fv, None, S, **kw)

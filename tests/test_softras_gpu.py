@@ -16,10 +16,27 @@ from oracle import softras_oracle
 
 pytestmark = pytest.mark.gpu
 
-# end to end the projection adds fp32 rounding of the vertex positions themselves
-# (|x| ~ 1, 6e-8) which the 1/sigma = 1e5 slope of the fragments amplifies
-IMG_TOL = 2e-4
-GRAD_TOL = 2e-4
+# End to end the camera stage hands fp32 vertex positions to the rasterizer (|x| ~ 1: 6e-8 of
+# rounding), which the 1/sigma = 1e5 slope of the fragments amplifies.  That cost is measured per
+# case -- the fp64 oracle with only its camera stage evaluated in fp32 (`stage_dtype`) against the
+# all-fp64 oracle -- and recorded beside the kernels' error in gpurun_out/softras_parity.json; the
+# kernels must stay within FLOOR_FACTOR times that floor (their own projection rounds differently
+# from the oracle's fp32 one, so the two errors are of one size, not equal), and never beyond
+# IMG_TOL / GRAD_TOL.  Measured: kernels 1e-6 .. 1.7e-5, floor 1e-6 .. 3.9e-5 -- the kernels sit at
+# the floor, so the call's error is the camera stage's fp32 rounding, not the rasterizer's.
+IMG_TOL = 2e-5
+GRAD_TOL = 5e-5
+FLOOR_FACTOR = 3.0
+_LOG = []
+
+
+def _record(name, **kw):
+    import json
+    _LOG.append(dict(test=name, **{k: float(v) for k, v in kw.items()}))
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(out):
+        with open(os.path.join(out, "softras_parity.json"), "w") as fh:
+            json.dump(_LOG, fh, indent=1)
 
 
 def _inputs(sub, B, seed):
@@ -58,11 +75,23 @@ def test_soft_neural_renderer_modes_match_oracle(mode):
     want = softras_oracle.render(vo, f, co, to, img_size=img, background=(0.2, 0.3, 0.4),
                                  texture_type="vertex" if mode == "vertex" else "surface")
     (want * w.double()).sum().backward()
-    assert rel_err(out.detach().cpu(), want.detach()) < IMG_TOL
-    assert rel_err(vg.grad.cpu(), vo.grad) < GRAD_TOL
-    assert rel_err(cg.grad.cpu(), co.grad) < GRAD_TOL
-    if tex is not None:
-        assert rel_err(tg.grad.cpu(), to.grad) < GRAD_TOL
+    # the floor: same oracle, camera stage in fp32
+    vf = v.double().requires_grad_(True)
+    cf = cams.double().requires_grad_(True)
+    tf = tex.double().requires_grad_(True) if tex is not None else None
+    floor = softras_oracle.render(vf, f, cf, tf, img_size=img, background=(0.2, 0.3, 0.4),
+                                  texture_type="vertex" if mode == "vertex" else "surface",
+                                  stage_dtype=torch.float32)
+    (floor * w.double()).sum().backward()
+    err = dict(img=rel_err(out.detach().cpu(), want.detach()), grad_v=rel_err(vg.grad.cpu(), vo.grad),
+               grad_cam=rel_err(cg.grad.cpu(), co.grad),
+               grad_tex=rel_err(tg.grad.cpu(), to.grad) if tex is not None else 0.0)
+    flo = dict(img=rel_err(floor.detach(), want.detach()), grad_v=rel_err(vf.grad, vo.grad),
+               grad_cam=rel_err(cf.grad, co.grad), grad_tex=rel_err(tf.grad, to.grad) if tex is not None else 0.0)
+    _record("softras_%s" % mode, **err, **{"floor_" + k: x for k, x in flo.items()})
+    for k, cap in (("img", IMG_TOL), ("grad_v", GRAD_TOL), ("grad_cam", GRAD_TOL), ("grad_tex", GRAD_TOL)):
+        assert err[k] < cap, (k, err[k])
+        assert err[k] < max(FLOOR_FACTOR * flo[k], 1e-5), (k, err[k], flo[k])
 
 
 def test_lighting_and_mutators():
