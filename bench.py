@@ -338,8 +338,10 @@ def train_step_leg(args, device, world, rank):
             "batch_per_rank": o.batch_size, "rendered_images_per_pass": 16 * o.batch_size, "steps": steps,
             "ms_per_step": 1e3 * dt / steps, "dataset_images_per_s_per_rank": per_rank,
             "dataset_images_per_s": per_rank * world, "ranks": world,
-            "gradient_all_reduce": ("RCCL via DistributedDataParallel over %d ranks"
-                                    % torch.distributed.get_world_size()) if world > 1 else "none (one rank)"}
+            "gradient_all_reduce": ("%s via DistributedDataParallel over %d ranks"
+                                    % ("RCCL" if torch.distributed.get_backend() == "nccl" else
+                                       torch.distributed.get_backend(), torch.distributed.get_world_size()))
+            if world > 1 else "none (one rank)"}
 
 
 def pmc_traffic(args, kernel):
@@ -361,13 +363,25 @@ def pmc_traffic(args, kernel):
 
 def main():
     args = parse()
+    if os.environ.get("SV3D_BENCH_WATCHDOG"):
+        # diagnostic: dump every thread's Python stack to stderr if the run is still going after N seconds
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["SV3D_BENCH_WATCHDOG"]), repeat=False)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         import torch.distributed as dist
+        # SV3D_DIST_BACKEND=gloo+cuda rehearses the multi-rank run on one GPU (ranks share it,
+        # collectives through gloo); the default is RCCL, one GPU per rank
+        rehearsal = os.environ.get("SV3D_DIST_BACKEND") == "gloo+cuda"
+        if rehearsal:
+            local_rank %= max(torch.cuda.device_count(), 1)
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
     device = torch.device("cuda", local_rank)

@@ -193,8 +193,10 @@ class ShapeTrainer(train_utils.Trainer):
         loss = (per_cam * cam_probs).sum(0).mean()
         loss = loss + 0.05 * F.cross_entropy(cam_logits, per_cam.detach().argmin(0))
         if o.seg_train and Np > 0:
-            # through the (possibly DDP-wrapped) module's forward, never its bare parameter
-            seg_map = self.part_basis_generator()[None].expand(B2, -1, -1)
+            # through the (possibly DDP-wrapped) module's forward, never its bare parameter; the
+            # argument is ignored (mesh_net.py:612 `forward(self, x=None)`) but a wrapper bound to a
+            # GPU needs one positional input to place
+            seg_map = self.part_basis_generator(pred_v.new_zeros(1))[None].expand(B2, -1, -1)
             if o.share_renders:
                 seg = self.vertex_seg_renderer.render_parts(vs, fs, proj_cam, torch.cat([seg_map] * Nc))
             else:
@@ -240,6 +242,8 @@ def parse(argv=None):
     p.add_argument('--dt_loss_wt', type=float, default=0.01, help='weight of the texture-flow distance-map loss')
     p.add_argument('--host_dt', type=int, default=0,
                    help="1: distance maps per mask with scipy on the host, as the reference computes them")
+    p.add_argument('--print_checksum', type=int, default=0,
+                   help='every rank prints the sum of its weights after training (ranks must agree)')
     p.add_argument('--share_renders', type=int, default=1,
                    help='1: silhouette from the RGB pass, eight part maps per pass, texture sets shared by the '
                         'camera hypotheses; 0: the '
@@ -272,6 +276,10 @@ def main(argv=None):
         renders = 1 + (parts + 7) // 8 if o.share_renders else 2 + parts
         print('steps %d, %.1f ms/step, %.1f dataset images/s over %d rank(s) (%d rendered images x %d renders per step per rank)'
               % (steps, 1e3 * dt / max(steps, 1), steps * o.batch_size * t.env.world_size / dt, t.env.world_size, Bn, renders))
+    if o.print_checksum:
+        mods = [train_utils.unwrap(t.model), train_utils.unwrap(t.part_basis_generator)]
+        total = sum(float(p.detach().double().sum()) for m in mods for p in m.parameters())
+        print('rank %d weight checksum %.12e' % (t.env.rank, total), flush=True)
     return t
 
 

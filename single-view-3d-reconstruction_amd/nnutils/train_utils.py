@@ -83,7 +83,13 @@ def init_distributed(backend=None, gpu_id=0):
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', str(gpu_id)))
+    backend = backend or os.environ.get('SV3D_DIST_BACKEND') or None
     use_cuda = torch.cuda.is_available() and backend != 'gloo'
+    if backend == 'gloo+cuda':
+        # rehearsal of the multi-rank step on fewer GPUs than ranks: ranks share the GPUs round
+        # robin and gradients travel through gloo (RCCL refuses two ranks on one device)
+        use_cuda, backend = torch.cuda.is_available(), 'gloo'
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)
     if use_cuda:
         if world == 1:
             local_rank = gpu_id

@@ -54,7 +54,7 @@ def _make_trainer(opts, env, n=16):
             # the basis has no input (mesh_net.py:612 `forward(self, x=None)`): it is reached through
             # the wrapper's call, as the step harness reaches it -- reading `.module.w` instead would
             # leave its gradient out of the all-reduce and the ranks' copies would drift apart
-            self.total_loss = self.crit(self.part_basis_generator() * self.model(self.x), self.y)
+            self.total_loss = self.crit(self.part_basis_generator(self.x.new_zeros(1)) * self.model(self.x), self.y)
 
         def set_input(self, batch):
             self.x, self.y = (t.to(self.device) for t in batch)
