@@ -64,6 +64,8 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=3.0, help="budget of the dense silhouette leg")
     ap.add_argument("--no-extras", action="store_true", help="headline only: no api / chamfer / train_step legs")
     ap.add_argument("--train-steps", type=int, default=12, help="timed steps of the train_step leg")
+    ap.add_argument("--train-args", default="", help="extra examples/cmr_synthetic.py flags for the train_step leg "
+                                                     "(rehearsals with a smaller network)")
     return ap.parse_args()
 
 
@@ -308,7 +310,8 @@ def train_step_leg(args, device, world, rank):
     cmr = _load_cmr_module()
     tmp = tempfile.mkdtemp(prefix="sv3d_bench_")
     o = cmr.parse(["--batch_size", "4", "--seg_train", "1", "--print_scalars", "0", "--checkpoint_dir", tmp,
-                   "--name", "bench", "--dataset_size", "1024", "--save_latest_freq", "1000000"])
+                   "--name", "bench", "--dataset_size", "1024", "--save_latest_freq", "1000000"]
+                  + args.train_args.split())
     o.epoch_fraction = 1.0
     from nnutils import train_utils
     env = train_utils.init_distributed(gpu_id=device.index)

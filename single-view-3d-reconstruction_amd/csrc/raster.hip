@@ -1019,7 +1019,12 @@ __global__ __launch_bounds__(kThreads) void raster_backward_kernel(
     const bool only_alpha = MODE == SV3D_TEX_NONE && P.alpha_only;
     // colour + alpha planes of image b, or its alpha plane alone
     const float *grad_b = grad_rgba + (size_t)b * (only_alpha ? 1 : NC + 1) * plane;
-    const size_t alpha_plane = only_alpha ? 0 : NC * plane;
+    const float *grad_alpha = grad_b + (only_alpha ? 0 : NC * plane);      // alpha plane of image b
+    // per-pixel loads below take a wave-uniform base and a 32-bit byte offset (planes and the saved
+    // array of one image stay far below 4 GB), which the hardware adds itself
+    auto at32 = [](const float *base, unsigned index) -> float {
+        return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(base) + index * 4u);
+    };
     auto fetch = [&]() {                            // inputs of the pixel at the current (rx, ry)
         PixIn in;
         in.valid = ry_f < bh_f;
@@ -1033,20 +1038,21 @@ __global__ __launch_bounds__(kThreads) void raster_backward_kernel(
             in.xl = in.yl = 0.f;
         }
         const unsigned prow = (unsigned)(row0 + (int)cy), pcol = (unsigned)(col0 + (int)cx);
-        const unsigned pix = prow * (unsigned)S + pcol;
-        const unsigned gpix = P.aa == 2 ? (prow >> 1) * (unsigned)H + (pcol >> 1) : pix;
+        // rows, columns and sizes are at most 4096: 24-bit multiplies (one v_mad_u32_u24 each)
+        const unsigned pix = __umul24(prow, (unsigned)S) + pcol;
+        const unsigned gpix = P.aa == 2 ? __umul24(prow >> 1, (unsigned)H) + (pcol >> 1) : pix;
         in.ssum = in.m = 0.f;
 #pragma unroll
         for (int c = 0; c < NC; ++c) in.col[c] = in.gch[c] = 0.f;
-        in.ga = grad_b[gpix + alpha_plane];
+        in.ga = at32(grad_alpha, gpix);
         if (MODE == SV3D_TEX_NONE) {
-            in.A = saved_b[pix];
+            in.A = at32(saved_b, pix);
         } else if (NC == 3) {
-            const float2 *sp = (const float2 *)(saved_b + pix * 6u);
+            const float2 *sp = reinterpret_cast<const float2 *>(reinterpret_cast<const char *>(saved_b) + pix * 24u);
             const float2 a0 = sp[0], a1 = sp[1], a2 = sp[2];
             in.A = a0.x; in.ssum = a0.y; in.m = a1.x; in.col[0] = a1.y; in.col[1] = a2.x; in.col[2] = a2.y;
         } else {
-            const float4 *sp = (const float4 *)(saved_b + pix * 12u);
+            const float4 *sp = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(saved_b) + pix * 48u);
             const float4 a0 = sp[0], a1 = sp[1], a2 = sp[2];
             in.A = a0.x; in.ssum = a0.y; in.m = a0.z;
             const float cs[8] = {a0.w, a1.x, a1.y, a1.z, a1.w, a2.x, a2.y, a2.z};
@@ -1055,7 +1061,7 @@ __global__ __launch_bounds__(kThreads) void raster_backward_kernel(
         }
         if (MODE != SV3D_TEX_NONE) {
 #pragma unroll
-            for (int c = 0; c < NC; ++c) in.gch[c] = grad_b[gpix + c * plane];
+            for (int c = 0; c < NC; ++c) in.gch[c] = at32(grad_b + c * plane, gpix);
         }
         // advance to the pixel 64 positions further
         rx_f += adv_x;

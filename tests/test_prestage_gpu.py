@@ -107,6 +107,27 @@ def test_scatter_variants_match_index_add_and_repeat_bitwise(V, F, fan):
     assert torch.equal(g1, vg.grad) and torch.equal(c1, cg.grad)
 
 
+@pytest.mark.parametrize("V,F", [(300, 2000), (20000, 40000)])      # sorted scatter; scan-form fallback
+def test_out_of_range_face_indices_are_clamped_the_same_way_forward_and_backward(V, F):
+    """Indices outside [0, V-1] read vertex 0 or V-1 in the gathers; both scatter forms must send
+    the gradient of such a corner to that same vertex (the backward is the gather's transpose)."""
+    import sv3d
+    faces = _random_topology(V, F, 3, 0)
+    bad = faces.clone()
+    bad[5, 1], bad[17, 0], bad[F - 1, 2] = V + 7, -3, 10 * V
+    clamped = bad.clamp(0, V - 1)
+    gen = torch.Generator().manual_seed(9)
+    v = torch.randn(2, V, 3, generator=gen).cuda()
+    g = torch.randn(2, F, 3, 3, generator=gen).cuda()
+    outs = []
+    for f in (bad, clamped):
+        x = v.clone().requires_grad_(True)
+        out = sv3d.face_gather(x, f[None].cuda(), scale=SCALE, shift=SHIFT)
+        (out * g).sum().backward()
+        outs.append((out.detach(), x.grad))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
 @pytest.mark.parametrize("mode", ["mask", "rgb_lit", "rgb_ambient", "vertex"])
 def test_fused_renderer_call_matches_staged_call(mode):
     """SoftNeuralRenderer through the fused ops against the same call assembled from separate
