@@ -241,11 +241,13 @@ def api_leg(args, device, rank):
     f_all = f.expand(B, -1, -1).contiguous()
 
     def headline_config():
+        vg.grad = cg.grad = None               # as the trainer's zero_grad(set_to_none=True): no accumulation pass
         out = sv3d.render(vg, cg, f, None, H, offset_z=5.0, scale=(1.0, -1.0, 1.0), shift=(0.0, 0.0, 2.732),
                           anti_aliasing=args.anti_aliasing, sigma_val=args.sigma, alpha_only=True)
         out.backward(grad)
 
     def reference_defaults():
+        vg.grad = cg.grad = None
         renderer(vg, f_all, cg).backward(grad)
 
     res = {}
