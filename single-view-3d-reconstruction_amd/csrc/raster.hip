@@ -51,6 +51,12 @@ constexpr int kThreads = 256;
 constexpr int kRec = 32;          // floats per face record (128 B, eight float4)
 constexpr int kRec4 = kRec / 4;
 constexpr int kTile = 16;         // tile side in raster pixels
+#ifndef SV3D_SPLIT_MAX_TILES
+#define SV3D_SPLIT_MAX_TILES 2048               // two waves per block up to this many tiles per launch
+#endif
+#ifndef SV3D_DIRECT_BOXES
+#define SV3D_DIRECT_BOXES 1
+#endif
 #ifndef SV3D_LIST_CAP
 #define SV3D_LIST_CAP 128
 #endif
@@ -511,6 +517,10 @@ __attribute__((amdgpu_waves_per_eu(MODE == SV3D_TEX_VERTEX8 ? 7 : 8))) void rast
     const uint2 *__restrict__ gbox, const float *__restrict__ tex, float *__restrict__ rgba,
     float *__restrict__ saved, CoarseBins CB)
 {
+    // Small launches (SPLIT == 2) are bound by latency, not by instructions: they test every face's
+    // pixel box at once (one round trip to memory) instead of the group boxes first and then the
+    // boxes of the touched groups (two dependent round trips, fewer instructions).
+    constexpr bool kDirectBoxes = SV3D_DIRECT_BOXES && SPLIT == 2;
     constexpr int NT = kThreads * SPLIT;        // threads per workgroup
     constexpr int NW = 4 * SPLIT;               // waves per workgroup
     __shared__ float4 s_rec[kListCap * kRecPad4];
@@ -677,7 +687,7 @@ __attribute__((amdgpu_waves_per_eu(MODE == SV3D_TEX_VERTEX8 ? 7 : 8))) void rast
     SV3D_STAMP(0);
     for (int fbase = 0; fbase < ncand; fbase += 64 * 64) {
         const int nmask = (min(ncand - fbase, 64 * 64) + 63) >> 6;  // at most 64 masks per pass
-        if (!COARSE) {
+        if (!COARSE && !kDirectBoxes) {
             // Face groups first: lane l tests the box of group l (the 64 faces of mask l) against
             // the tile; only the groups that touch it have their faces' boxes loaded, dealt out to
             // the waves in turn, up to four per wave and trip so that the loads overlap.  A tile no
@@ -1388,7 +1398,7 @@ int raster_forward_impl(const sv3d_raster_params *p, const float *face_vertices,
     if (ev_start) (void)hipEventRecord(ev_start, s);
     // two waves per block while the grid is small enough that single waves set the kernel's span;
     // the remainder-carrying variants when S is not a power of two
-    const bool split = (long)tiles * tiles * d.B <= 2048;      // measured: 12 and 16 images of 256^2 are faster unsplit
+    const bool split = (long)tiles * tiles * d.B <= SV3D_SPLIT_MAX_TILES;      // measured: 12 and 16 images of 256^2 are faster unsplit
     const bool lo = (d.S & (d.S - 1)) != 0;
 #define SV3D_LAUNCH_FWD2(M, SP, LO_, CO_)                                                              \
     hipLaunchKernelGGL((raster_forward_kernel<M, SP, LO_, CO_>), grid, dim3(SP * kThreads), 0, s, d, rec,  \
