@@ -583,11 +583,14 @@ struct SoftRasterizeFn : public torch::autograd::Function<SoftRasterizeFn> {
         ctx->saved_data["fv_dtype"] = (int64_t)fv.scalar_type();
         ctx->saved_data["need_tex"] = has_tex && tex->requires_grad();
         ctx->mark_non_differentiable({std::get<1>(out), std::get<2>(out)});
+        // no zero-filled stand-ins for the gradients of the two saved buffers (megabytes each)
+        ctx->set_materialize_grads(false);
         return {std::get<0>(out), std::get<1>(out), std::get<2>(out)};
     }
 
     static variable_list backward(AutogradContext *ctx, variable_list grads)
     {
+        if (!grads[0].defined()) return {Tensor(), Tensor(), Tensor(), Tensor()};
         const auto saved = ctx->get_saved_variables();
         const Tensor &tex = saved[0];
         const auto icfg = ctx->saved_data["icfg"].toIntVector();
@@ -622,11 +625,13 @@ struct RenderFn : public torch::autograd::Function<RenderFn> {
         ctx->saved_data["fcfg"] = fcfg.vec();
         ctx->saved_data["need_tex"] = has_tex && tex->requires_grad();
         ctx->mark_non_differentiable({std::get<1>(out), std::get<2>(out)});
+        ctx->set_materialize_grads(false);
         return {std::get<0>(out), std::get<1>(out), std::get<2>(out)};
     }
 
     static variable_list backward(AutogradContext *ctx, variable_list grads)
     {
+        if (!grads[0].defined()) return {Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor()};
         const auto saved = ctx->get_saved_variables();
         const Tensor &v = saved[0], &c = saved[1], &f = saved[2], &tex = saved[3];
         const auto mesh_cfg = ctx->saved_data["mesh_cfg"].toDoubleVector();
@@ -657,6 +662,9 @@ struct ChamferFn : public torch::autograd::Function<ChamferFn> {
         auto out = op.call(a, b);
         ctx->save_for_backward({a, b, std::get<2>(out), std::get<3>(out)});
         ctx->mark_non_differentiable({std::get<2>(out), std::get<3>(out)});
+        // a distance output that took no part in the loss keeps an undefined gradient: the backward
+        // then skips that side (the reference uses dist2 alone, nnutils/loss_utils.py:87-88)
+        ctx->set_materialize_grads(false);
         return {std::get<0>(out), std::get<1>(out), std::get<2>(out), std::get<3>(out)};
     }
 
@@ -665,7 +673,7 @@ struct ChamferFn : public torch::autograd::Function<ChamferFn> {
         const auto saved = ctx->get_saved_variables();
         const Tensor &a = saved[0], &b = saved[1];
         const bool need1 = ctx->needs_input_grad(0), need2 = ctx->needs_input_grad(1);
-        if (!need1 && !need2) return {Tensor(), Tensor()};
+        if ((!need1 && !need2) || (!grads[0].defined() && !grads[1].defined())) return {Tensor(), Tensor()};
         static auto op = find_op<std::tuple<Tensor, Tensor>(const Tensor &, const Tensor &, const optional<Tensor> &,
                                                             const optional<Tensor> &, const Tensor &, const Tensor &,
                                                             bool, bool)>("sv3d::chamfer_nn_backward");

@@ -190,4 +190,8 @@ def render(vertices, cams, faces, textures=None, image_size=256, *, offset_z=0.0
     icfg, fcfg = raster_config(image_size, anti_aliasing, mode, res, fill_back, alpha_only, background_color,
                                near, far, eps, sigma_val, dist_eps, gamma_val)
     rgba = _ops.render(vertices, cams, _faces_i32(faces), textures, _mesh_cfg(offset_z, scale, shift), icfg, fcfg)[0]
-    return rgba[:, -1] if alpha_only else rgba
+    if not alpha_only:
+        return rgba
+    # without textures the image IS the alpha plane: a view, whose backward is a view too (selecting
+    # a plane would make autograd build a zero-filled image around the incoming gradient)
+    return rgba.squeeze(1) if mode == L.SV3D_TEX_NONE else rgba[:, -1]
