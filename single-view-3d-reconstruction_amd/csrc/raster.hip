@@ -32,7 +32,8 @@
 // Diagnostic build only: per-workgroup start / end stamps and phase stamps of the forward kernel.
 __device__ unsigned long long g_trace[4 * 16384];
 __device__ unsigned long long g_phase[8 * 4096];
-#define SV3D_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 4096) g_phase[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define SV3D_WG_ID (blockIdx.y * gridDim.x + blockIdx.x)
+#define SV3D_STAMP(i) do { if (threadIdx.x == 0 && SV3D_WG_ID < 4096) g_phase[SV3D_WG_ID * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 extern "C" int sv3d_debug_read_trace(void *host_out, size_t bytes)
 {
     return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_trace), bytes, 0, hipMemcpyDeviceToHost);
@@ -56,6 +57,12 @@ constexpr int kTile = 16;         // tile side in raster pixels
 #endif
 #ifndef SV3D_DIRECT_BOXES
 #define SV3D_DIRECT_BOXES 1
+#endif
+#ifndef SV3D_SPLIT_ADJACENT
+#define SV3D_SPLIT_ADJACENT 1
+#endif
+#ifndef SV3D_SPIRAL
+#define SV3D_SPIRAL 1
 #endif
 #ifndef SV3D_LIST_CAP
 #define SV3D_LIST_CAP 128
@@ -506,6 +513,30 @@ __global__ __launch_bounds__(kThreads) void raster_coarse_kernel(
 // ------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------
+// Tile of a workgroup's tile number.  Workgroups start in id order and a CU takes the next one as
+// soon as it has room, so the numbering is a schedule.  Small launches (`rings`, even tile counts)
+// number their tiles in square rings from the image centre outwards (ring k holds the 8k + 4 tiles
+// at Chebyshev distance k + 1/2 from the centre): the tiles an object usually covers start first
+// and the empty border is left for the tail.  Large launches lose by that (the heavy tiles then
+// share their CUs); they go row by row, every tile row rotated by 5 more columns than the row
+// above, so that the tiles one CU receives do not share a screen column.
+__device__ inline void tile_position(int tile, int tiles_x, bool rings, int &tile_x, int &tile_y)
+{
+    if (rings && !(tiles_x & 1)) {
+        int k = (int)(__builtin_amdgcn_sqrtf((float)tile) * 0.5f);     // raw v_sqrt_f32, corrected below
+        if (4 * k * k > tile) --k;
+        else if (4 * (k + 1) * (k + 1) <= tile) ++k;
+        const int j = tile - 4 * k * k, w = 2 * k + 1;
+        const int side = (j >= w) + (j >= 2 * w) + (j >= 3 * w), off = j - side * w;
+        const int lo = (tiles_x >> 1) - 1 - k, hi = (tiles_x >> 1) + k;
+        tile_x = side == 0 ? lo + off : (side == 1 ? hi : (side == 2 ? hi - off : lo));
+        tile_y = side == 0 ? lo : (side == 1 ? lo + off : (side == 2 ? hi : hi - off));
+    } else {
+        tile_y = tile / tiles_x;
+        tile_x = (tile % tiles_x + 5 * tile_y) % tiles_x;
+    }
+}
+
 // SPLIT = 1: four waves, one per 8x8 block of the tile.  SPLIT = 2 (small grids): eight waves, two
 // per block, which take alternate hits of the block's face list and merge their partial pixel
 // states through LDS at the end -- the kernel's span at small batches is its longest single wave
@@ -535,19 +566,37 @@ __attribute__((amdgpu_waves_per_eu(MODE == SV3D_TEX_VERTEX8 ? 7 : 8))) void rast
     const unsigned long long trace_t0 = __builtin_amdgcn_s_memrealtime();
 #endif
     const int tiles_x = (P.S + kTile - 1) / kTile;
-    const int b = blockIdx.x % P.B;
-    const int tb = P.TB == P.B ? b : b % P.TB;          // texture set of this image
-    const int tile = blockIdx.x / P.B;
+    // small launches come as a grid (image, tile), large ones as a line with the image index fastest
+    const int b = SPLIT == 2 ? (int)blockIdx.x : (int)(blockIdx.x % P.B);
+    const int tile = SPLIT == 2 ? (int)blockIdx.y : (int)(blockIdx.x / P.B);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int S = P.S, F = P.F;
-    // ... and every tile row is rotated by 5 more columns than the row above, so that the tiles
-    // one CU receives do not share a screen column either.
-    const int tile_y = tile / tiles_x;
-    const int tile_c0 = ((tile % tiles_x + 5 * tile_y) % tiles_x) * kTile, tile_r0 = tile_y * kTile;
+    const uint2 *pbox_b = pbox + (size_t)b * F;
+    // Small launches send the first box loads of the binning pass out before anything else: the way
+    // through the memory system is the longest single wait of a tile, and the tile arithmetic
+    // below fits inside it.
+    constexpr int kEarly = 3;                           // masks per wave loaded ahead (3 * NW * 64 faces)
+    constexpr bool kEarlyBoxes = kDirectBoxes && MODE == SV3D_TEX_NONE;     // colour modes lack the registers
+    uint2 bx_early[kEarly];
+    if (kEarlyBoxes) {
+#pragma unroll
+        for (int k = 0; k < kEarly; ++k) {
+            const int f = (wave + NW * k) * 64 + lane;
+            bx_early[k] = f < F ? pbox_b[f] : make_uint2(0xffff7fffu, 0xffff7fffu);
+        }
+    }
+    const int tb = P.TB == P.B ? b : b % P.TB;          // texture set of this image
+    int tile_x, tile_y;
+    tile_position(tile, tiles_x, SV3D_SPIRAL && SPLIT == 2, tile_x, tile_y);
+    const int tile_c0 = tile_x * kTile, tile_r0 = tile_y * kTile;
     // lane -> pixel of the wave's 8x8 block; lanes 4q..4q+3 form the 2x2 quad q
     const int quad = lane >> 2, sub = lane & 3;
+#if SV3D_SPLIT_ADJACENT
+    const int blk = SPLIT == 2 ? wave >> 1 : wave, part = SPLIT == 2 ? wave & 1 : 0;
+#else
     const int blk = wave & 3, part = wave >> 2;         // block of the tile, share of its face list
+#endif
     const int blk_c0 = tile_c0 + (blk & 1) * 8, blk_r0 = tile_r0 + (blk >> 1) * 8;
     const int col = blk_c0 + (quad & 3) * 2 + (sub & 1);
     const int row = blk_r0 + (quad >> 2) * 2 + (sub >> 1);
@@ -561,7 +610,6 @@ __attribute__((amdgpu_waves_per_eu(MODE == SV3D_TEX_VERTEX8 ? 7 : 8))) void rast
     pixel_centre(blk_c0 + 7, blk_r0, S, P.inv_S, bxb, byb);
 
     const float4 *rec_b = rec + (size_t)b * F * kRec4;
-    const uint2 *pbox_b = pbox + (size_t)b * F;
     const float zref = ((const float *)rec_b)[27];
     const float c0shift = (P.far_plane - zref) * P.inv_range;
 
@@ -731,8 +779,23 @@ __attribute__((amdgpu_waves_per_eu(MODE == SV3D_TEX_VERTEX8 ? 7 : 8))) void rast
                     }
                 }
             }
-        } else
-        for (int m0 = wave; m0 < nmask; m0 += 8 * NW) {             // eight masks per wave per trip
+        } else {
+        auto test_box = [&](int mi, uint2 box) {
+            if (mi < nmask) {                                       // wave-uniform
+                int c0, c1, r0, r1;
+                unpack_box(box, c0, c1, r0, r1);
+                const bool hit = !(c1 < tile_c0 || c0 > tc1 || r1 < tile_r0 || r0 > tr1);
+                const unsigned long long mask = __ballot(hit);
+                if (lane == 0) s_mask[mi] = mask;
+            }
+        };
+        int m_first = wave;
+        if (kEarlyBoxes && fbase == 0) {                            // the boxes loaded at the start
+#pragma unroll
+            for (int k = 0; k < kEarly; ++k) test_box(wave + NW * k, bx_early[k]);
+            m_first += kEarly * NW;
+        }
+        for (int m0 = m_first; m0 < nmask; m0 += 8 * NW) {          // eight masks per wave per trip
             uint2 bx[8];
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
@@ -741,16 +804,8 @@ __attribute__((amdgpu_waves_per_eu(MODE == SV3D_TEX_VERTEX8 ? 7 : 8))) void rast
                 bx[k] = f >= 0 ? pbox_b[f] : make_uint2(0xffff7fffu, 0xffff7fffu);   // empty box
             }
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const int mi = m0 + NW * k;
-                if (mi < nmask) {                                   // wave-uniform
-                    int c0, c1, r0, r1;
-                    unpack_box(bx[k], c0, c1, r0, r1);
-                    const bool hit = !(c1 < tile_c0 || c0 > tc1 || r1 < tile_r0 || r0 > tr1);
-                    const unsigned long long mask = __ballot(hit);
-                    if (lane == 0) s_mask[mi] = mask;
-                }
-            }
+            for (int k = 0; k < 8; ++k) test_box(m0 + NW * k, bx[k]);
+        }
         }
         __syncthreads();
         SV3D_STAMP(1);
@@ -858,12 +913,12 @@ __attribute__((amdgpu_waves_per_eu(MODE == SV3D_TEX_VERTEX8 ? 7 : 8))) void rast
     }
     SV3D_STAMP(6);
 #ifdef SV3D_TRACE
-    if (lane == 0 && blockIdx.x < 4096 && wave < 4) {
+    if (lane == 0 && SV3D_WG_ID < 4096 && part == 0) {
         unsigned hwid;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
         unsigned xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        unsigned long long *t = g_trace + ((size_t)blockIdx.x * 4 + wave) * 4;
+        unsigned long long *t = g_trace + ((size_t)SV3D_WG_ID * 4 + blk) * 4;
         t[0] = trace_t0;
         t[1] = __builtin_amdgcn_s_memrealtime();
         t[2] = ((unsigned long long)xcc << 32) | hwid;
@@ -1400,9 +1455,10 @@ int raster_forward_impl(const sv3d_raster_params *p, const float *face_vertices,
     // the remainder-carrying variants when S is not a power of two
     const bool split = (long)tiles * tiles * d.B <= SV3D_SPLIT_MAX_TILES;      // measured: 12 and 16 images of 256^2 are faster unsplit
     const bool lo = (d.S & (d.S - 1)) != 0;
+    const dim3 grid_split((unsigned)d.B, (unsigned)(tiles * tiles));   // (image, tile) for the small launches
 #define SV3D_LAUNCH_FWD2(M, SP, LO_, CO_)                                                              \
-    hipLaunchKernelGGL((raster_forward_kernel<M, SP, LO_, CO_>), grid, dim3(SP * kThreads), 0, s, d, rec,  \
-                       pbox, gbox, textures, rgba_out, saved, cb)
+    hipLaunchKernelGGL((raster_forward_kernel<M, SP, LO_, CO_>), SP == 2 ? grid_split : grid,          \
+                       dim3(SP * kThreads), 0, s, d, rec, pbox, gbox, textures, rgba_out, saved, cb)
 #define SV3D_LAUNCH_FWD(M)                                                                             \
     do {                                                                                               \
         if (coarse && lo) SV3D_LAUNCH_FWD2(M, 1, true, true);                                          \

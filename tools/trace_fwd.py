@@ -66,6 +66,10 @@ se = (hwid >> 13) & 0x7
 simd = (hwid >> 4) & 0x3
 print("workgroups traced", n, "kernel span %.1f us" % end.max())
 print("wave start: min %.1f p50 %.1f p99 %.1f max %.1f us" % (start.min(), np.median(start), np.percentile(start, 99), start.max()))
+wg_start = np.sort(start.min(1))
+print("workgroups started by t us: " + "  ".join("%g:%d" % (x, int((wg_start <= x).sum())) for x in (0.5, 1, 1.5, 2, 3, 4, 5, 6, 8, 10, 12, 14)))
+wg_end = np.sort(end.max(1))
+print("workgroups finished by t us: " + "  ".join("%g:%d" % (x, int((wg_end <= x).sum())) for x in (2, 4, 6, 8, 10, 12, 14, 16, 18, 20, 22)))
 print("wave dur  : mean %.1f p50 %.1f p90 %.1f p99 %.1f max %.1f us" % (dur.mean(), np.median(dur), np.percentile(dur, 90), np.percentile(dur, 99), dur.max()))
 print("visits/wave: mean %.1f max %d ; correlation dur~visits %.2f" % (visits.mean(), visits.max(), np.corrcoef(dur.ravel(), visits.ravel())[0, 1]))
 wg_sum, wg_max = visits.sum(1), visits.max(1)
