@@ -32,7 +32,7 @@
 // Diagnostic build only: per-workgroup start / end stamps and phase stamps of the forward kernel.
 __device__ unsigned long long g_trace[4 * 16384];
 __device__ unsigned long long g_phase[8 * 4096];
-#define SV3D_WG_ID (blockIdx.y * gridDim.x + blockIdx.x)
+#define SV3D_WG_ID ((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x)
 #define SV3D_STAMP(i) do { if (threadIdx.x == 0 && SV3D_WG_ID < 4096) g_phase[SV3D_WG_ID * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 extern "C" int sv3d_debug_read_trace(void *host_out, size_t bytes)
 {
@@ -520,9 +520,11 @@ __global__ __launch_bounds__(kThreads) void raster_coarse_kernel(
 // and the empty border is left for the tail.  Large launches lose by that (the heavy tiles then
 // share their CUs); they go row by row, every tile row rotated by 5 more columns than the row
 // above, so that the tiles one CU receives do not share a screen column.
-__device__ inline void tile_position(int tile, int tiles_x, bool rings, int &tile_x, int &tile_y)
+__device__ inline void tile_position(int gx, int gy, int tiles_x, bool rings, int &tile_x, int &tile_y)
 {
+    // (gx, gy): the workgroup's place in the grid of tiles; its number there is gy * tiles_x + gx
     if (rings && !(tiles_x & 1)) {
+        const int tile = gy * tiles_x + gx;
         int k = (int)(__builtin_amdgcn_sqrtf((float)tile) * 0.5f);     // raw v_sqrt_f32, corrected below
         if (4 * k * k > tile) --k;
         else if (4 * (k + 1) * (k + 1) <= tile) ++k;
@@ -532,8 +534,8 @@ __device__ inline void tile_position(int tile, int tiles_x, bool rings, int &til
         tile_x = side == 0 ? lo + off : (side == 1 ? hi : (side == 2 ? hi - off : lo));
         tile_y = side == 0 ? lo : (side == 1 ? lo + off : (side == 2 ? hi : hi - off));
     } else {
-        tile_y = tile / tiles_x;
-        tile_x = (tile % tiles_x + 5 * tile_y) % tiles_x;
+        tile_y = gy;
+        tile_x = (gx + 5 * gy) % tiles_x;
     }
 }
 
@@ -566,9 +568,8 @@ __attribute__((amdgpu_waves_per_eu(MODE == SV3D_TEX_VERTEX8 ? 7 : 8))) void rast
     const unsigned long long trace_t0 = __builtin_amdgcn_s_memrealtime();
 #endif
     const int tiles_x = (P.S + kTile - 1) / kTile;
-    // small launches come as a grid (image, tile), large ones as a line with the image index fastest
-    const int b = SPLIT == 2 ? (int)blockIdx.x : (int)(blockIdx.x % P.B);
-    const int tile = SPLIT == 2 ? (int)blockIdx.y : (int)(blockIdx.x / P.B);
+    // grid (image, tile column, tile row): workgroups start with the image index running fastest
+    const int b = blockIdx.x;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int S = P.S, F = P.F;
@@ -586,9 +587,14 @@ __attribute__((amdgpu_waves_per_eu(MODE == SV3D_TEX_VERTEX8 ? 7 : 8))) void rast
             bx_early[k] = f < F ? pbox_b[f] : make_uint2(0xffff7fffu, 0xffff7fffu);
         }
     }
+    // ... and large launches the boxes of the image's first 64 face groups, one per lane
+    // (the RGB modes lack the registers to hold either across the tile arithmetic)
+    constexpr bool kEarlyGroups = !COARSE && !kDirectBoxes && (MODE == SV3D_TEX_NONE || MODE == SV3D_TEX_VERTEX8);
+    uint2 gb_early = make_uint2(0xffff7fffu, 0xffff7fffu);
+    if (kEarlyGroups && lane < face_groups(F)) gb_early = gbox[(size_t)b * face_groups(F) + lane];
     const int tb = P.TB == P.B ? b : b % P.TB;          // texture set of this image
     int tile_x, tile_y;
-    tile_position(tile, tiles_x, SV3D_SPIRAL && SPLIT == 2, tile_x, tile_y);
+    tile_position(blockIdx.y, blockIdx.z, tiles_x, SV3D_SPIRAL && SPLIT == 2, tile_x, tile_y);
     const int tile_c0 = tile_x * kTile, tile_r0 = tile_y * kTile;
     // lane -> pixel of the wave's 8x8 block; lanes 4q..4q+3 form the 2x2 quad q
     const int quad = lane >> 2, sub = lane & 3;
@@ -744,7 +750,7 @@ __attribute__((amdgpu_waves_per_eu(MODE == SV3D_TEX_VERTEX8 ? 7 : 8))) void rast
             bool touch = false;
             if (lane < nmask) {
                 int c0, c1, r0, r1;
-                unpack_box(gbox_b[lane], c0, c1, r0, r1);
+                unpack_box(kEarlyGroups && fbase == 0 ? gb_early : gbox_b[lane], c0, c1, r0, r1);
                 touch = !(c1 < tile_c0 || c0 > tc1 || r1 < tile_r0 || r0 > tr1);
             }
             unsigned long long todo = __ballot(touch);
@@ -1438,7 +1444,6 @@ int raster_forward_impl(const sv3d_raster_params *p, const float *face_vertices,
         hipLaunchKernelGGL(raster_setup_kernel, sgrid, dim3(kThreads), 0, s, d, face_vertices, rec, pbox, gbox);
     }
     const int tiles = (d.S + kTile - 1) / kTile;
-    dim3 grid((unsigned)tiles * tiles * d.B);
     float *saved = static_cast<float *>(pixel_saved);
     CoarseBins cb = {nullptr, nullptr, 0, 0, 0};
     const bool coarse = coarse_enabled(d);
@@ -1455,10 +1460,10 @@ int raster_forward_impl(const sv3d_raster_params *p, const float *face_vertices,
     // the remainder-carrying variants when S is not a power of two
     const bool split = (long)tiles * tiles * d.B <= SV3D_SPLIT_MAX_TILES;      // measured: 12 and 16 images of 256^2 are faster unsplit
     const bool lo = (d.S & (d.S - 1)) != 0;
-    const dim3 grid_split((unsigned)d.B, (unsigned)(tiles * tiles));   // (image, tile) for the small launches
+    const dim3 grid3((unsigned)d.B, (unsigned)tiles, (unsigned)tiles);  // tiles <= 256, batch <= 65535
 #define SV3D_LAUNCH_FWD2(M, SP, LO_, CO_)                                                              \
-    hipLaunchKernelGGL((raster_forward_kernel<M, SP, LO_, CO_>), SP == 2 ? grid_split : grid,          \
-                       dim3(SP * kThreads), 0, s, d, rec, pbox, gbox, textures, rgba_out, saved, cb)
+    hipLaunchKernelGGL((raster_forward_kernel<M, SP, LO_, CO_>), grid3, dim3(SP * kThreads), 0, s, d, rec, \
+                       pbox, gbox, textures, rgba_out, saved, cb)
 #define SV3D_LAUNCH_FWD(M)                                                                             \
     do {                                                                                               \
         if (coarse && lo) SV3D_LAUNCH_FWD2(M, 1, true, true);                                          \

@@ -88,6 +88,13 @@ per = [(visits[key == k].sum(), end[key == k].max(), (key == k).sum()) for k in 
 per = np.array(per, dtype=np.float64)
 print("per-CU visits: mean %.0f max %.0f min %.0f ; per-CU finish time: mean %.1f max %.1f min %.1f us ; waves per CU mean %.1f max %.0f"
       % (per[:, 0].mean(), per[:, 0].max(), per[:, 0].min(), per[:, 1].mean(), per[:, 1].max(), per[:, 1].min(), per[:, 2].mean(), per[:, 2].max()))
+ks = key * 4 + simd
+us = np.unique(ks)
+pv = np.array([visits[ks == k].sum() for k in us], dtype=np.float64)
+print("per-SIMD visits (traced waves): mean %.0f max %.0f min %.0f p90 %.0f ; SIMDs seen %d ; waves per SIMD mean %.1f"
+      % (pv.mean(), pv.max(), pv.min(), np.percentile(pv, 90), len(us), visits.size / len(us)))
+for w in range(visits.shape[1]):
+    print("  traced wave %d sits on SIMD: %s" % (w, np.bincount(simd[:, w], minlength=4).tolist()))
 late = np.argsort(-end.max(1))[:5]
 for i in late:
     print("  late wg %d: start %.1f end %.1f visits %s cu-key %d" % (i, start[i].min(), end[i].max(), visits[i].tolist(), key[i, 0]))
