@@ -999,6 +999,9 @@ __global__ __launch_bounds__(kThreads) void raster_backward_kernel(
     float *__restrict__ gfv, float *__restrict__ gtex)
 {
     extern __shared__ float s_dyn[];            // SURFACE: per wave, texel gradient tables + texel values
+#ifdef SV3D_TRACE
+    const unsigned long long trace_t0 = __builtin_amdgcn_s_memrealtime();
+#endif
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1023,6 +1026,10 @@ __global__ __launch_bounds__(kThreads) void raster_backward_kernel(
     unpack_box(pbox[gf], col0, col1, row0, row1);
     const int bw = col1 - col0 + 1, bh = row1 - row0 + 1;
     const int npix = (live && bw > 0 && bh > 0) ? bw * bh : 0;
+#ifdef SV3D_TRACE
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     // the record and the box are here
+    const unsigned long long trace_ta = __builtin_amdgcn_s_memrealtime() + (unsigned long long)(r.p0x != 12345.f ? 0 : 1);
+#endif
     const float inv_bw = bw > 0 ? rcp((float)bw) : 0.f;     // the two fix-ups below absorb its last-bit error
 
     // SURFACE: the face's texel gradients accumulate in wave-private LDS tables.  Lanes of one
@@ -1145,6 +1152,10 @@ __global__ __launch_bounds__(kThreads) void raster_backward_kernel(
 
     PixIn nxt;
     if (npix > half * 64) nxt = fetch();
+#ifdef SV3D_TRACE
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     // the first pixels are here
+    const unsigned long long trace_tb = __builtin_amdgcn_s_memrealtime();
+#endif
     for (int base = half * 64; base < npix; base += kStride) {
         const PixIn in = nxt;
         if (base + kStride < npix) nxt = fetch();   // wave-uniform
@@ -1259,6 +1270,19 @@ __global__ __launch_bounds__(kThreads) void raster_backward_kernel(
         acc[6] = fmaf(f2, g.dx, acc[6]); acc[7] = fmaf(f2, g.dy, acc[7]);
     }
 
+#ifdef SV3D_TRACE
+    if (lane == 0 && blockIdx.x * 4 + wave < 16384) {       // stamp at the end of the pixel loop
+        unsigned hwid, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        unsigned long long *t = g_trace + ((size_t)blockIdx.x * 4 + wave) * 4;
+        t[0] = trace_t0;
+        t[1] = __builtin_amdgcn_s_memrealtime();
+        t[2] = ((unsigned long long)xcc << 32) | hwid;
+        // pixels of the box, and when the record and the first pixels had arrived (10 ns units)
+        t[3] = (unsigned long long)npix | (((trace_ta - trace_t0) & 0xffffull) << 32) | (((trace_tb - trace_t0) & 0xffffull) << 48);
+    }
+#endif
     float tot[9];
 #pragma unroll
     for (int i = 0; i < 9; ++i)                     // silhouettes carry no depth gradient
