@@ -135,6 +135,8 @@ class SyntheticCUB(torch.utils.data.Dataset):
 
 
 class ShapeTrainer(train_utils.Trainer):
+    graph_inputs = ('imgs', 'masks')
+
     def init_dataset(self):
         o = self.opts
         ds = SyntheticCUB(o.dataset_size, o.img_size, seed=1)
@@ -159,6 +161,7 @@ class ShapeTrainer(train_utils.Trainer):
     def define_criterion(self):
         self.triangle_loss_fn = sr.LaplacianLoss(self.verts0, self.faces0).to(self.device)
         self.flatten_loss_fn = sr.FlattenLoss(self.faces0).to(self.device)
+        self.mirror = torch.tensor([-1.0, 1.0, 1.0], device=self.device)    # x -> -x (main.py:317)
 
     def set_input(self, batch):
         img, mask = batch
@@ -215,8 +218,7 @@ class ShapeTrainer(train_utils.Trainer):
                 dts = torch.cat([dts, dts.flip(-1)])
             loss = loss + o.dt_loss_wt * loss_utils.texture_dt_loss(flow, dts[:, None])
         Bh = B2 // 2
-        mirror = pred_v.new_tensor([-1.0, 1.0, 1.0])
-        loss = loss + o.chamf_loss_wt * loss_utils.chamfer_loss(pred_v[:Bh].detach(), pred_v[Bh:] * mirror)
+        loss = loss + o.chamf_loss_wt * loss_utils.chamfer_loss(pred_v[:Bh].detach(), pred_v[Bh:] * self.mirror)
         loss = loss + 5e-3 * self.triangle_loss_fn(pred_v).mean() + 5e-4 * self.flatten_loss_fn(pred_v).mean()
         self.total_loss = loss
 

@@ -20,6 +20,14 @@ Clipping runs on the already averaged gradients, so every rank takes the same st
 alone writes snapshots and logs; scalars are averaged over ranks every `print_freq` steps.
 BatchNorm statistics stay per rank (no SyncBN), as a single-GPU run of the reference has them
 per batch.
+
+`--cuda_graph 1` (single process): a step of the reference's size issues several hundred kernel
+launches and is bound by the host issuing them, not by the GPU.  After `GRAPH_EAGER_STEPS`
+ordinary steps the trainer captures forward + loss + backward once in a HIP graph
+(`torch.cuda.CUDAGraph`) over static copies of the inputs a subclass names in `graph_inputs`, and
+from then on replays it; unscale, clipping, the optimizer steps and the scaler update stay eager
+(GradScaler's step reads its inf check on the host).  Everything in the captured part must be
+free of host synchronisation and of shapes that change from step to step.
 """
 import argparse
 import gc
@@ -57,6 +65,9 @@ def add_training_flags(parser=None):
     p.add_argument('--amp_dtype', choices=['fp16', 'bf16'], default='fp16',
                    help='autocast type; the reference uses fp16 with a GradScaler (train_utils.py:182-214)')
     p.add_argument('--seed', type=int, default=0)
+    p.add_argument('--cuda_graph', type=int, default=0,
+                   help='1: after a few eager steps, capture forward + loss + backward of a step in a HIP graph '
+                        'and replay it (single process, constant batch shape; the optimizer steps stay eager)')
     return p
 
 
@@ -110,8 +121,14 @@ def unwrap(module):
 
 
 class Trainer(object):
+    # names of the attributes `set_input` fills that `forward` reads: the inputs of a captured step
+    graph_inputs = ()
+    GRAPH_EAGER_STEPS = 3
+
     def __init__(self, opts, env=None):
         self.opts = opts
+        self._graph = None              # captured step: {'graph', 'static'}
+        self._graph_eager_steps = 0
         self.env = env if env is not None else init_distributed(gpu_id=getattr(opts, 'gpu_id', 0))
         self.device = self.env.device
         self.gpu_id = self.env.local_rank if self.device.type == 'cuda' else None
@@ -232,22 +249,71 @@ class Trainer(object):
         dist.all_reduce(flag, op=dist.ReduceOp.MAX)
         return bool(flag.item() > 0)
 
-    def train_step(self, batch, total_steps, scaler):
-        opts = self.opts
-        self.set_input(batch)
-        if self.skip_step():
-            return False
+    def _zero_grads(self):
         self.optimizer.zero_grad(set_to_none=True)
         if self._second_optimizer():
             self.optimizer_2.zero_grad(set_to_none=True)
+
+    def _forward_backward(self, total_steps, scaler):
+        opts = self.opts
         use_amp = self.device.type == 'cuda' and bool(getattr(opts, 'amp', 1))
         amp_dtype = torch.bfloat16 if getattr(opts, 'amp_dtype', 'fp16') == 'bf16' else torch.float16
         with torch.autocast(device_type=self.device.type, dtype=amp_dtype if self.device.type == 'cuda' else None,
                             enabled=use_amp):
             self.forward(total_steps)
+        scaler.scale(self.total_loss).backward()
+
+    def _graph_wanted(self):
+        return bool(getattr(self.opts, 'cuda_graph', 0)) and self.device.type == 'cuda' \
+            and not self.env.distributed and len(self.graph_inputs) > 0
+
+    def _forward_backward_graphed(self, total_steps, scaler):
+        """Forward + loss + backward of this step from the captured graph (captured here on first use)."""
+        if self._graph is None:
+            static = {name: torch.empty_like(getattr(self, name)) for name in self.graph_inputs}
+            for name, buf in static.items():
+                buf.copy_(getattr(self, name))
+                setattr(self, name, buf)
+            # torch's recipe: a few uncaptured passes on a side stream, then the capture; the gradients
+            # of these passes are dropped, the weights do not move.  The last eager step's loss still
+            # holds its autograd graph, whose gradient-accumulation nodes belong to the default stream.
+            self.total_loss = None
+            side = torch.cuda.Stream(self.device)
+            side.wait_stream(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(side):
+                for _ in range(2):
+                    self._zero_grads()
+                    self._forward_backward(total_steps, scaler)
+            torch.cuda.current_stream(self.device).wait_stream(side)
+            self._zero_grads()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                self._forward_backward(total_steps, scaler)
+            self._graph = {'graph': graph, 'static': static, 'loss': self.total_loss}
+        else:
+            for name, buf in self._graph['static'].items():
+                src = getattr(self, name)
+                if src.shape != buf.shape or src.dtype != buf.dtype:
+                    raise RuntimeError('--cuda_graph needs a constant batch: %s is %s, the captured step has %s'
+                                       % (name, tuple(src.shape), tuple(buf.shape)))
+                buf.copy_(src, non_blocking=True)
+                setattr(self, name, buf)
+        self._graph['graph'].replay()
+        self.total_loss = self._graph['loss']
+
+    def train_step(self, batch, total_steps, scaler):
+        opts = self.opts
+        self.set_input(batch)
+        if self.skip_step():
+            return False
+        if self._graph_wanted() and self._graph_eager_steps >= self.GRAPH_EAGER_STEPS:
+            self._forward_backward_graphed(total_steps, scaler)
+        else:
+            self._graph_eager_steps += 1
+            self._zero_grads()
+            self._forward_backward(total_steps, scaler)
         # the reference's smoothed loss (:194), kept on the device: no host sync per step
         self.smoothed_total_loss = self.smoothed_total_loss * 0.99 + 0.01 * self.total_loss.detach().float()
-        scaler.scale(self.total_loss).backward()
         clip = getattr(opts, 'grad_clip', 0.1)
         scaler.unscale_(self.optimizer)
         torch.nn.utils.clip_grad_norm_(self.model.parameters(), clip)
@@ -265,7 +331,9 @@ class Trainer(object):
         dataset_size = len(self.dataloader)
         total_steps = dataset_size * opts.num_pretrain_epochs
         use_amp = self.device.type == 'cuda' and bool(getattr(opts, 'amp', 1))
-        scaler = torch.amp.GradScaler(self.device.type, enabled=use_amp)
+        if getattr(self, '_scaler', None) is None:      # one scaler per trainer: a captured step holds its scale tensor
+            self._scaler = torch.amp.GradScaler(self.device.type, enabled=use_amp)
+        scaler = self._scaler
         frac = getattr(opts, 'epoch_fraction', 0.1)
         self.images_seen = 0
         t_log = time.time()

@@ -36,3 +36,4 @@ def test_bench_prints_one_json_line_with_roofline_and_cpu_baseline():
     assert [r["points"] for r in j["chamfer"]] == [642, 642, 2048, 8192] and all(r["tflops"] > 0 for r in j["chamfer"])
     t = j["train_step"]
     assert t["ranks"] == 1 and t["steps"] == 4 and t["dataset_images_per_s"] > 10
+    assert t["hip_graph"]["dataset_images_per_s"] > 10 and t["hip_graph"]["ms_per_step"] > 0
