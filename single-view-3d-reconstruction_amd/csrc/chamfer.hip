@@ -23,6 +23,15 @@
 
 namespace {
 
+#ifndef SV3D_CHAMFER_SMALL
+#define SV3D_CHAMFER_SMALL 1
+#endif
+#ifndef SV3D_CHAMFER_SMALL_WGS
+#define SV3D_CHAMFER_SMALL_WGS 512             // ... used up to this many workgroups of the tiled kernel (measured crossover)
+#endif
+#ifndef SV3D_CHAMFER_SMALL_QW
+#define SV3D_CHAMFER_SMALL_QW 2                 // queries per wave of the small-call kernel
+#endif
 constexpr int kThreads = 256;
 constexpr int kTile = 1024;          // candidates staged per LDS tile (16 KiB)
 constexpr int kGroup = 8;            // candidates per group minimum
@@ -155,6 +164,82 @@ __global__ __launch_bounds__(64 * kWaves) void chamfer_nn_kernel(
         if (qi < nq) {
             dout[qi] = bd;
             iout[qi] = bj;
+        }
+    }
+}
+
+// Lexicographic (distance, index) minimum over the 64 lanes with a fixed DPP tree; valid in lane 63.
+template <int CTRL, int ROW_MASK>
+__device__ inline void dpp_lexmin(float &d, int &i)
+{
+    // lanes the row mask leaves out, and lanes whose source lies outside their row, read their own value
+    const float od = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(d), __float_as_int(d), CTRL, ROW_MASK, 0xf, false));
+    const int oi = __builtin_amdgcn_update_dpp(i, i, CTRL, ROW_MASK, 0xf, false);
+    const bool take = od < d || (od == d && oi < i);
+    d = take ? od : d;
+    i = take ? oi : i;
+}
+
+// Calls so small that the tiled kernel leaves most of the chip idle (the reference's own: two
+// halves of a batch of 4-8 meshes with 642 vertices, nnutils/loss_utils.py:85-86) are nothing but
+// latency there: stage, barrier, scan, barrier, merge.  Here a wave works alone -- no LDS, no
+// barrier: its lanes hold the candidate cloud between them (CL points each, point c * 64 + lane in
+// slot c), the wave takes QW queries one after the other, every lane scans its own candidates in
+// increasing index with a strict `<`, and a (distance, index) lexicographic minimum over the lanes
+// gives the lowest index among the minima -- the same result, bit for bit, as the tiled kernel.
+template <int CL, int QW>
+__global__ __launch_bounds__(kThreads) void chamfer_nn_small_kernel(
+    const float *__restrict__ xyz1, const float *__restrict__ xyz2, int N, int M,
+    float *__restrict__ dist1, float *__restrict__ dist2,
+    int32_t *__restrict__ idx1, int32_t *__restrict__ idx2, int waves_dir0)
+{
+    const int b = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int wave_b = __builtin_amdgcn_readfirstlane((int)blockIdx.x * (kThreads / 64) + (int)(threadIdx.x >> 6));
+    const bool dir1 = wave_b >= waves_dir0;
+    const int w = dir1 ? wave_b - waves_dir0 : wave_b;
+    const int nq = dir1 ? M : N;
+    const int nc = dir1 ? N : M;
+    const int q0 = w * QW;
+    if (q0 >= nq) return;                           // whole wave
+    const float *qp = (dir1 ? xyz2 + (size_t)b * M * 3 : xyz1 + (size_t)b * N * 3);
+    const float *cp = (dir1 ? xyz1 + (size_t)b * N * 3 : xyz2 + (size_t)b * M * 3);
+    float *dout = (dir1 ? dist2 + (size_t)b * M : dist1 + (size_t)b * N);
+    int32_t *iout = (dir1 ? idx2 + (size_t)b * M : idx1 + (size_t)b * N);
+
+    float cx[CL], cy[CL], cz[CL];
+#pragma unroll
+    for (int c = 0; c < CL; ++c) {
+        const int j = min(c * 64 + lane, nc - 1);   // slots past the cloud repeat its last point and are skipped below
+        cx[c] = cp[3 * j];
+        cy[c] = cp[3 * j + 1];
+        cz[c] = cp[3 * j + 2];
+    }
+#pragma unroll
+    for (int k = 0; k < QW; ++k) {
+        const int qi = min(q0 + k, nq - 1);         // wave-uniform
+        const float qx = qp[3 * qi], qy = qp[3 * qi + 1], qz = qp[3 * qi + 2];
+        float best = INFINITY;
+        int bi = 0x7fffffff;                        // a lane without candidates never wins a tie
+#pragma unroll
+        for (int c = 0; c < CL; ++c) {
+            const float dx = cx[c] - qx;
+            const float dy = cy[c] - qy;
+            const float dz = cz[c] - qz;
+            const float d = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+            const bool lt = c * 64 + lane < nc && d < best;
+            best = lt ? d : best;
+            bi = lt ? c * 64 + lane : bi;
+        }
+        dpp_lexmin<0xB1, 0xf>(best, bi);            // quad_perm [1,0,3,2]
+        dpp_lexmin<0x4E, 0xf>(best, bi);            // quad_perm [2,3,0,1]
+        dpp_lexmin<0x141, 0xf>(best, bi);           // row_half_mirror
+        dpp_lexmin<0x140, 0xf>(best, bi);           // row_mirror: every lane of a row holds the row's minimum
+        dpp_lexmin<0x142, 0xa>(best, bi);           // row_bcast:15: rows 1 and 3 take in the row before them
+        dpp_lexmin<0x143, 0xc>(best, bi);           // row_bcast:31: rows 2 and 3 take in rows 0 and 1
+        if (lane == 63 && q0 + k < nq) {
+            dout[q0 + k] = best;
+            iout[q0 + k] = bi;
         }
     }
 }
@@ -312,6 +397,22 @@ extern "C" int sv3d_chamfer_forward(const float *xyz1, const float *xyz2, int32_
     // at most a workgroup per CU: sixteen waves split every tile, so that the scan of a wave -- the
     // whole run time of such a call -- is a quarter as long (4 x 642 points: 8.4 -> about 6 us)
     const bool tiny = (long)(b0 + b1) * B <= 256;
+    // ... and when both clouds fit the lanes of one wave (16 points each), waves that work alone
+    const int cmax = N > M ? N : M;
+    if (SV3D_CHAMFER_SMALL && (long)(b0 + b1) * B <= SV3D_CHAMFER_SMALL_WGS && cmax <= 1024) {
+        constexpr int QW = SV3D_CHAMFER_SMALL_QW;
+        const int w0 = (N + QW - 1) / QW, w1 = (M + QW - 1) / QW;
+        const dim3 sgrid((w0 + w1 + kThreads / 64 - 1) / (kThreads / 64), B);
+#define SV3D_LAUNCH_SMALL(CL_)                                                                         \
+    hipLaunchKernelGGL((chamfer_nn_small_kernel<CL_, QW>), sgrid, block, 0, s, xyz1, xyz2, N, M, dist1, dist2, \
+                       idx1, idx2, w0)
+        if (cmax <= 256) SV3D_LAUNCH_SMALL(4);
+        else if (cmax <= 512) SV3D_LAUNCH_SMALL(8);
+        else if (cmax <= 768) SV3D_LAUNCH_SMALL(12);
+        else SV3D_LAUNCH_SMALL(16);
+#undef SV3D_LAUNCH_SMALL
+        return launch_status();
+    }
     if (Q == 4)
         hipLaunchKernelGGL((chamfer_nn_kernel<4, 4>), grid, block, 0, s, xyz1, xyz2, N, M, dist1, dist2, idx1, idx2, b0);
     else if (Q == 2)

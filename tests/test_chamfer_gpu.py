@@ -36,7 +36,11 @@ def _check(a, b):
 
 
 @pytest.mark.parametrize("B,N,M", [(1, 1, 1), (2, 642, 642), (3, 157, 2051), (2, 2048, 2048),
-                                   (1, 1025, 63), (5, 64, 4097)])
+                                   (1, 1025, 63), (5, 64, 4097),
+                                   # calls served by the waves-work-alone kernel: every candidate slot
+                                   # count (4, 8, 12, 16 per lane) and its edges, odd query counts
+                                   (4, 256, 256), (3, 257, 512), (2, 768, 769), (1, 1024, 1023), (16, 642, 100),
+                                   (7, 3, 65), (16, 1024, 1024), (17, 1024, 1024)])
 def test_forward_random_clouds(B, N, M):
     rng = np.random.default_rng(B * 1000 + N + M)
     _check(rng.standard_normal((B, N, 3)).astype(np.float32),
@@ -53,6 +57,13 @@ def test_forward_ties_duplicates_and_zero_distances():
     d1, _, i1, _ = _check(lat, dup)
     assert np.all(d1 == 0) and np.array_equal(i1[0], np.arange(512))    # first copy wins
     _check(dup, dup[:, ::-1].copy())
+    # the same on clouds small enough for the kernel whose lanes split the candidates: the minimum
+    # is attained in several lanes at once and the lowest index must win
+    small = lat[:, :64]
+    dup = np.concatenate([small, small, small], 1)
+    d1, _, i1, _ = _check(np.repeat(small, 4, 0), np.repeat(dup, 4, 0))
+    assert np.all(d1 == 0) and np.array_equal(i1[3], np.arange(64))
+    _check(np.repeat(dup, 4, 0), np.repeat(dup[:, ::-1], 4, 0).copy())
 
 
 def test_forward_mesh_vertices_and_mirror():

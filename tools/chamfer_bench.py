@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Timing of the Chamfer entry points through the C ABI: python tools/chamfer_bench.py"""
+"""Timing of the Chamfer entry points through the C ABI: python tools/chamfer_bench.py [other_build.so]"""
 import ctypes
 import os
 import sys
@@ -10,11 +10,11 @@ import torch
 
 from sv3d import _lib as L, workmodel
 
-lib = L.lib()
+lib = ctypes.CDLL(os.path.abspath(sys.argv[1])) if len(sys.argv) > 1 else L.lib()
 dev = torch.device("cuda:0")
 vp = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
 stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-for B, N, M in [(4, 642, 642), (64, 642, 642), (8, 2048, 2048), (64, 2048, 2048), (2, 8192, 8192), (16, 8192, 8192),
+for B, N, M in [(4, 642, 642), (8, 642, 642), (16, 642, 642), (32, 642, 642), (64, 642, 642), (4, 162, 162), (16, 1024, 1024), (8, 2048, 2048), (64, 2048, 2048), (2, 8192, 8192), (16, 8192, 8192),
                 (64, 2562, 2562)]:
     g = torch.Generator().manual_seed(5)
     a = torch.randn(B, N, 3, generator=g).to(dev)
