@@ -54,6 +54,8 @@ def parse():
     ap.add_argument("--image-size", type=int, default=256)
     ap.add_argument("--subdivide", type=int, default=3)
     ap.add_argument("--sigma", type=float, default=1e-4)
+    ap.add_argument("--preroll-ms", dest="preroll_ms", type=float, default=80.0,
+                    help="untimed repetition of the step before the warm-up steps, to bring the clocks up")
     ap.add_argument("--event_stride", type=int, default=10,
                     help="record HIP events around the kernels on every n-th timed step")
     ap.add_argument("--gamma", type=float, default=1e-4)
@@ -434,11 +436,15 @@ def main():
     # Kernel durations come from HIP events recorded on the kernels' stream inside the timed
     # region.  An event pair costs a few microseconds of stream time, a fifth of this step, so
     # only every `stride`-th step carries them; the other steps use the plain entry points.
-    # (short runs: every 4th step, so that a 20-step run still rests on five samples)
+    # Such a step times ONE of the two kernels, forward and backward in turn, which halves that
+    # cost.  (Short runs: every 4th step, so that a 20-step run still rests on 3 + 2 samples.)
     stride = max(1, args.event_stride) if K >= 100 else min(4, max(1, args.event_stride))
     timed_steps = [i for i in range(K) if i % stride == 0]
-    fe = ev.create(2 * len(timed_steps))
-    be = ev.create(2 * len(timed_steps))
+    if len(timed_steps) < 2 and K >= 2:
+        timed_steps = [0, K - 1]
+    n_fwd, n_bwd = (len(timed_steps) + 1) // 2, len(timed_steps) // 2
+    fe = ev.create(2 * max(n_fwd, 1))
+    be = ev.create(2 * max(n_bwd, 1))
     slot = {i: j for j, i in enumerate(timed_steps)}
     pp = ctypes.byref(p)
 
@@ -452,11 +458,15 @@ def main():
             L.check(lib.sv3d_raster_forward(pp, a_fv, a_tex, a_rgba, a_rec, a_saved, stream), "fwd")
             L.check(lib.sv3d_raster_backward(pp, a_tex, a_rec, a_saved, a_grad, a_gfv, a_gtex, a_ws, a_wsb,
                                              stream), "bwd")
-        else:
+        elif j % 2 == 0:                              # this step's forward kernel carries the events
             L.check(lib.sv3d_raster_forward_timed(pp, a_fv, a_tex, a_rgba, a_rec, a_saved, stream,
-                                                  fe[2 * j], fe[2 * j + 1]), "fwd")
+                                                  fe[j], fe[j + 1]), "fwd")
+            L.check(lib.sv3d_raster_backward(pp, a_tex, a_rec, a_saved, a_grad, a_gfv, a_gtex, a_ws, a_wsb,
+                                             stream), "bwd")
+        else:                                         # ... this one's backward kernel
+            L.check(lib.sv3d_raster_forward(pp, a_fv, a_tex, a_rgba, a_rec, a_saved, stream), "fwd")
             L.check(lib.sv3d_raster_backward_timed(pp, a_tex, a_rec, a_saved, a_grad, a_gfv, a_gtex, a_ws,
-                                                   a_wsb, stream, be[2 * j], be[2 * j + 1]), "bwd")
+                                                   a_wsb, stream, be[j - 1], be[j]), "bwd")
 
     def barrier():
         if world > 1:
@@ -472,12 +482,22 @@ def main():
         gc.collect()
         torch.cuda.empty_cache()
 
-    for _ in range(W):
-        step()
     # no pause of Python's cyclic collector inside the timed region: a full collection of the
-    # process's objects takes longer than the GPU's launch queue can cover
+    # process's objects takes longer than the GPU's launch queue can cover.  It runs before the
+    # warm-up, not after it: the GPU would sit idle through it and start the timed steps cold.
     gc.collect()
     gc.disable()
+    # The card raises its clocks only after tens of milliseconds of continuous work: the same
+    # kernels run 7 % slower in the first milliseconds after an idle spell (23.8 against 22.3 us
+    # for the forward), which a 20-step run of one millisecond would otherwise be measured in.
+    # The step is therefore repeated, untimed, for `--preroll-ms` before the W warm-up steps.
+    t_pre = time.perf_counter()
+    while (time.perf_counter() - t_pre) * 1e3 < args.preroll_ms:
+        for _ in range(64):
+            step()
+        torch.cuda.synchronize()
+    for _ in range(W):
+        step()
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -493,15 +513,15 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    n_ev = len(timed_steps)
-    fwd_ms = sum(ev.elapsed_ms(fe[2 * j], fe[2 * j + 1]) for j in range(n_ev)) / n_ev
-    bwd_ms = sum(ev.elapsed_ms(be[2 * j], be[2 * j + 1]) for j in range(n_ev)) / n_ev
+    fwd_ms = sum(ev.elapsed_ms(fe[2 * j], fe[2 * j + 1]) for j in range(n_fwd)) / n_fwd
+    # a one-step run has no backward sample: it reports the forward kernel
+    bwd_ms = sum(ev.elapsed_ms(be[2 * j], be[2 * j + 1]) for j in range(n_bwd)) / n_bwd if n_bwd else 0.0
     pairs = sum(workmodel.count_active_pairs(fv, S, args.sigma, 1e-10))
     f_flop, b_flop = workmodel.raster_flops(pairs, colour=args.mode != "none")
     if bwd_ms >= fwd_ms:
-        name, flop, ms = "raster_backward_kernel", b_flop, bwd_ms
+        name, flop, ms, n_ev = "raster_backward_kernel", b_flop, bwd_ms, n_bwd
     else:
-        name, flop, ms = "raster_forward_kernel", f_flop, fwd_ms
+        name, flop, ms, n_ev = "raster_forward_kernel", f_flop, fwd_ms, n_fwd
     achieved = flop / (ms * 1e-3) / 1e12
     roofline = {"bound": "valu", "kernel": name, "achieved": achieved,
                 "peak": workmodel.FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -511,7 +531,7 @@ def main():
                 "flop_per_pair": flop / max(pairs, 1),
                 "other_kernel": {"fwd_ms": fwd_ms, "bwd_ms": bwd_ms,
                                  "fwd_tflops": f_flop / (fwd_ms * 1e-3) / 1e12,
-                                 "bwd_tflops": b_flop / (bwd_ms * 1e-3) / 1e12}}
+                                 "bwd_tflops": b_flop / (bwd_ms * 1e-3) / 1e12 if bwd_ms > 0 else None}}
 
     if rank != 0:
         return
@@ -533,7 +553,8 @@ def main():
                                   B, args.image_size, args.image_size, " (2x AA)" if aa == 2 else "",
                                   {1: 42, 2: 162, 3: 642, 4: 2562}.get(args.subdivide, -1), F, args.sigma),
                    "batch_per_gpu": B, "image_size": args.image_size, "faces": F,
-                   "parallelism": "image-sharded x%d" % world},
+                   "parallelism": "image-sharded x%d" % world,
+                   "clock_preroll_ms": args.preroll_ms},
         "roofline": roofline,
     }
     out.update(extras)

@@ -368,7 +368,7 @@ __device__ inline void store_group_box(const DevParams &P, int b, int f, bool va
 
 __global__ __launch_bounds__(kThreads) void raster_setup_kernel(
     DevParams P, const float *__restrict__ fv, float4 *__restrict__ rec, uint2 *__restrict__ pbox,
-    uint2 *__restrict__ gbox)
+    uint2 *__restrict__ gbox)                   // gbox == nullptr: the forward will not read group boxes
 {
     const int b = blockIdx.y, f = blockIdx.x * kThreads + threadIdx.x;
     const bool valid = f < P.F;
@@ -379,7 +379,7 @@ __global__ __launch_bounds__(kThreads) void raster_setup_kernel(
         setup_face(P, gid, v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], v[8],
                    fv[(size_t)b * P.F * 9 + 2], rec, pbox, col0, col1, row0, row1);
     }
-    store_group_box(P, b, f, valid, col0, col1, row0, row1, gbox);
+    if (gbox) store_group_box(P, b, f, valid, col0, col1, row0, row1, gbox);
 }
 
 // Setup straight from the object-space mesh: each thread projects its face's three vertices
@@ -422,7 +422,7 @@ __global__ __launch_bounds__(kThreads) void raster_setup_mesh_kernel(
     setup_face(P, gid, o[0], o[1], o[2], o[3], o[4], o[5], o[6], o[7], o[8], zref, rec, pbox, col0, col1,
                row0, row1);
     }
-    store_group_box(P, b, f, valid, col0, col1, row0, row1, gbox);
+    if (gbox) store_group_box(P, b, f, valid, col0, col1, row0, row1, gbox);
 }
 
 __device__ inline void unpack_box(uint2 b, int &col0, int &col1, int &row0, int &row1)
@@ -1457,20 +1457,24 @@ int raster_forward_impl(const sv3d_raster_params *p, const float *face_vertices,
     const int nf = d.B * d.F;
     uint2 *gbox = pbox + nf;                        // [B][face_groups(F)], then the coarse bins
     const dim3 sgrid((d.F + kThreads - 1) / kThreads, d.B);
+    const int tiles = (d.S + kTile - 1) / kTile;
+    const bool coarse = coarse_enabled(d);
+    // two waves per block while the grid is small enough that single waves set the kernel's span
+    const bool split = (long)tiles * tiles * d.B <= SV3D_SPLIT_MAX_TILES;      // measured: 12 and 16 images of 256^2 are faster unsplit
+    // group boxes are read by the large launches without coarse bins only
+    uint2 *gbox_setup = (!coarse && !(SV3D_DIRECT_BOXES && split)) ? gbox : nullptr;
     if (mesh) {
         MeshArgs m;
         m.vertices = mesh->vertices; m.cams = mesh->cams; m.faces = mesh->faces;
         m.V = mesh->num_vertices; m.faces_batch = mesh->faces_batch; m.offset_z = mesh->offset_z;
         m.a = {mesh->scale[0], mesh->scale[1], mesh->scale[2], mesh->shift[0], mesh->shift[1], mesh->shift[2]};
         hipLaunchKernelGGL(raster_setup_mesh_kernel, sgrid, dim3(kThreads), 0, s, d, m,
-                           const_cast<float *>(face_vertices), rec, pbox, gbox);
+                           const_cast<float *>(face_vertices), rec, pbox, gbox_setup);
     } else {
-        hipLaunchKernelGGL(raster_setup_kernel, sgrid, dim3(kThreads), 0, s, d, face_vertices, rec, pbox, gbox);
+        hipLaunchKernelGGL(raster_setup_kernel, sgrid, dim3(kThreads), 0, s, d, face_vertices, rec, pbox, gbox_setup);
     }
-    const int tiles = (d.S + kTile - 1) / kTile;
     float *saved = static_cast<float *>(pixel_saved);
     CoarseBins cb = {nullptr, nullptr, 0, 0, 0};
-    const bool coarse = coarse_enabled(d);
     if (coarse) {
         const int bx = coarse_bins_x(d), nbins = bx * bx, cap = coarse_cap(d);
         int *count = reinterpret_cast<int *>(gbox + group_boxes(d));
@@ -1480,9 +1484,7 @@ int raster_forward_impl(const sv3d_raster_params *p, const float *face_vertices,
         cb = {list, count, bx, nbins, cap};
     }
     if (ev_start) (void)hipEventRecord(ev_start, s);
-    // two waves per block while the grid is small enough that single waves set the kernel's span;
     // the remainder-carrying variants when S is not a power of two
-    const bool split = (long)tiles * tiles * d.B <= SV3D_SPLIT_MAX_TILES;      // measured: 12 and 16 images of 256^2 are faster unsplit
     const bool lo = (d.S & (d.S - 1)) != 0;
     const dim3 grid3((unsigned)d.B, (unsigned)tiles, (unsigned)tiles);  // tiles <= 256, batch <= 65535
 #define SV3D_LAUNCH_FWD2(M, SP, LO_, CO_)                                                              \
