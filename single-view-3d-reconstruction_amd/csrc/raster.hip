@@ -90,7 +90,17 @@ struct DevParams {
     float inv_S;                  // 1 / S
     int alpha_fast;               // dist_eps so small that 1 + exp(-threshold/sigma) == 1 in fp32
     int alpha_only;               // silhouette mode: the image (and its gradient) is the alpha plane alone
+    unsigned inv_F;               // floor(2^32 / F): the image of a face index by a multiply, see image_of_face
 };
+
+// b = gf / F for 0 <= gf < B * F <= 2^29, without the ~25 instructions of an integer division (the
+// backward's waves start with it, eight to a SIMD): the multiply gives gf / F or one less.
+__device__ inline int image_of_face(int gf, int F, unsigned inv_F)
+{
+    int b = (int)__umulhi((unsigned)gf, inv_F);
+    b += (gf - b * F >= F) ? 1 : 0;
+    return b;
+}
 
 // Face record layout (float index):
 //  0..5   p0x p0y p1x p1y p2x p2y
@@ -114,6 +124,7 @@ struct FaceRec {
     float q0, q1, q2;
     int flags;
     float zref;
+    unsigned box_x, box_y;        // the pixel box as in the compact array
 };
 
 __device__ inline FaceRec load_rec(const float4 *r)
@@ -127,6 +138,51 @@ __device__ inline FaceRec load_rec(const float4 *r)
     o.f0x = e.x; o.f0y = e.y; o.f1x = e.z; o.f1y = e.w; o.f2x = h.z; o.f2y = h.w;
     o.iz0 = f.x; o.iz1 = f.y; o.iz2 = f.z; o.q0 = f.w;
     o.q1 = g.x; o.q2 = g.y; o.flags = __float_as_int(g.z); o.zref = g.w;
+    o.box_x = __float_as_uint(h.x); o.box_y = __float_as_uint(h.y);
+    return o;
+}
+
+// The record of a wave-uniform face through the scalar cache: all 128 bytes requested at once
+// (rec_request), waited for once (rec_wait), with whatever does not need the record placed between
+// the two calls.  (Written as loads of the record's float4s the compiler splits them into three
+// batches near their uses with a wait after each; scalar loads return in any order, so every wait
+// is for everything outstanding, and the batches become trips to memory in a row.)  Between the
+// two calls the four register blocks must not be touched: their values are not there yet.
+typedef float rec_f8 __attribute__((ext_vector_type(8)));
+struct RecRegs {
+    rec_f8 a, b, c, d;
+};
+
+__device__ inline void rec_request(const float4 *r, RecRegs &q)
+{
+    asm volatile("s_load_dwordx8 %0, %4, 0x0\n\t"
+                 "s_load_dwordx8 %1, %4, 0x20\n\t"
+                 "s_load_dwordx8 %2, %4, 0x40\n\t"
+                 "s_load_dwordx8 %3, %4, 0x60"
+                 : "=&s"(q.a), "=&s"(q.b), "=&s"(q.c), "=&s"(q.d)
+                 : "s"(r)
+                 : "memory");
+}
+
+__device__ inline FaceRec rec_wait(RecRegs &q, const void *done0, const void *done1, const void *done2)
+{
+    // The blocks are operands of the wait, so that no use of them can be placed ahead of it; the
+    // `done` values are results of the work meant to overlap the load: as inputs of the wait they
+    // are computed before it.
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+s"(q.a), "+s"(q.b), "+s"(q.c), "+s"(q.d)
+                 : "s"(done0), "s"(done1), "s"(done2)
+                 : "memory");
+    const rec_f8 a = q.a, b = q.b, c = q.c, d = q.d;
+    FaceRec o;
+    o.p0x = a[0]; o.p0y = a[1]; o.p1x = a[2]; o.p1y = a[3];
+    o.p2x = a[4]; o.p2y = a[5]; o.e0x = a[6]; o.e0y = a[7];
+    o.e1x = b[0]; o.e1y = b[1]; o.e2x = b[2]; o.e2y = b[3];
+    o.il0 = b[4]; o.il1 = b[5]; o.il2 = b[6]; o.inv_det = b[7];
+    o.f0x = c[0]; o.f0y = c[1]; o.f1x = c[2]; o.f1y = c[3];
+    o.iz0 = c[4]; o.iz1 = c[5]; o.iz2 = c[6]; o.q0 = c[7];
+    o.q1 = d[0]; o.q2 = d[1]; o.flags = __float_as_int(d[2]); o.zref = d[3];
+    o.box_x = __float_as_uint(d[4]); o.box_y = __float_as_uint(d[5]); o.f2x = d[6]; o.f2y = d[7];
     return o;
 }
 
@@ -1018,12 +1074,37 @@ __global__ __launch_bounds__(kThreads) void raster_backward_kernel(
     const bool live = gf_raw < P.B * P.F;
     if (HALVES == 1 && !live) return;           // whole wave; HALVES == 1 uses no block-level barrier
     const int gf = live ? gf_raw : P.B * P.F - 1;       // HALVES == 2: idle waves still reach the barrier
-    const int b = gf / P.F;
+    // Every kernel argument the wave will read is brought into registers first: a scalar load for
+    // one of them between the record's request and its wait would make that wait come early.
+    // (Not in the eight-channel mode, whose registers leave no room for either: measured +7 % there.)
+    constexpr bool kRequestAhead = MODE != SV3D_TEX_VERTEX8;
+    if (kRequestAhead)
+        asm volatile("" ::"s"(P.S), "s"(P.aa), "s"(P.TB), "s"(P.inv_S), "s"(P.inv_F), "s"(P.alpha_only), "s"(P.R),
+                     "s"(P.threshold), "s"(P.neg_l2e_over_sigma), "s"(P.inv_sigma), "s"(saved), "s"(grad_rgba),
+                     "s"(tex));
+    // The pixel box is taken from the record (floats 28..29), not from the compact box array: one
+    // request, one wait, then the pixel loads can go out.
+    RecRegs rec_regs;
+    if (kRequestAhead) rec_request(rec + (size_t)gf * kRec4, rec_regs);
+    // ---- nothing from here to rec_wait needs the record ----
+    const int b = image_of_face(gf, P.F, P.inv_F);
     const int tgf = P.TB == P.B ? gf : gf - (b - b % P.TB) * P.F;     // the face in its texture set
     const int S = P.S;
-    const FaceRec r = load_rec(rec + (size_t)gf * kRec4);
+    constexpr int NC = mode_channels(MODE);     // colour channels
+    constexpr int PP = MODE == SV3D_TEX_NONE ? 1 : (NC == 3 ? 6 : 12);   // saved floats per pixel
+    const float step = 2.f * P.inv_S;
+    const float *saved_b = saved + (size_t)b * S * S * PP;
+    const int H = P.aa == 2 ? S >> 1 : S;
+    const float gscale = P.aa == 2 ? 0.25f : 1.f;
+    const size_t plane = (size_t)H * H;
+    const bool only_alpha = MODE == SV3D_TEX_NONE && P.alpha_only;
+    // colour + alpha planes of image b, or its alpha plane alone
+    const float *grad_b = grad_rgba + (size_t)b * (only_alpha ? 1 : NC + 1) * plane;
+    const float *grad_alpha = grad_b + (only_alpha ? 0 : NC * plane);      // alpha plane of image b
+    const float fS = (float)S;
+    const FaceRec r = kRequestAhead ? rec_wait(rec_regs, saved_b, grad_b, grad_alpha) : load_rec(rec + (size_t)gf * kRec4);
     int col0, col1, row0, row1;
-    unpack_box(pbox[gf], col0, col1, row0, row1);
+    unpack_box(make_uint2(r.box_x, r.box_y), col0, col1, row0, row1);
     const int bw = col1 - col0 + 1, bh = row1 - row0 + 1;
     const int npix = (live && bw > 0 && bh > 0) ? bw * bh : 0;
 #ifdef SV3D_TRACE
@@ -1041,8 +1122,6 @@ __global__ __launch_bounds__(kThreads) void raster_backward_kernel(
     const bool staged = tex_staged(Ts);
     float *s_tex = s_dyn + wave * tex_lds_floats(Ts);
     float *s_val = s_tex + tex_grad_floats(Ts);
-    constexpr int NC = mode_channels(MODE);     // colour channels
-    constexpr int PP = MODE == SV3D_TEX_NONE ? 1 : (NC == 3 ? 6 : 12);   // saved floats per pixel
     float tv[3 * NC];                           // VERTEX modes: the face's per-corner colours
     if (MODE == SV3D_TEX_SURFACE) {
         for (int i = lane; i < ncopy * Ts * 3; i += 64) s_tex[i] = 0.f;
@@ -1069,14 +1148,15 @@ __global__ __launch_bounds__(kThreads) void raster_backward_kernel(
     // row wrap per lane; the per-pixel inputs of step i+1 are requested before step i is
     // evaluated so that their latency overlaps the arithmetic.
     const float bw_f = (float)bw, bh_f = (float)bh;
-    const float step = 2.f * P.inv_S;
     float xp0, yp0;
     pixel_centre(col0, row0, S, P.inv_S, xp0, yp0);
-    const float *saved_b = saved + (size_t)b * S * S * PP;
-    const int H = S / P.aa;
-    const float gscale = P.aa == 2 ? 0.25f : 1.f;
     constexpr int kStride = 64 * HALVES;        // pixels between two steps of one wave
-    const float adv_y = bw > 0 ? (float)(kStride / bw) : 0.f, adv_x = bw > 0 ? (float)(kStride % bw) : 0.f;
+    // kStride = adv_y * bw + adv_x, by the reciprocal and the same fix-ups as the lanes' start below
+    float adv_y = floorf(((float)kStride + 0.5f) * inv_bw);
+    float adv_x = fmaf(-adv_y, bw_f, (float)kStride);
+    if (adv_x < 0.f) { adv_y -= 1.f; adv_x += bw_f; }
+    if (adv_x >= bw_f) { adv_y += 1.f; adv_x -= bw_f; }
+    if (bw <= 0) adv_x = adv_y = 0.f;
     const float lane0 = (float)(half * 64 + lane);
     float ry_f = floorf((lane0 + 0.5f) * inv_bw);
     float rx_f = fmaf(-ry_f, bw_f, lane0);
@@ -1086,18 +1166,13 @@ __global__ __launch_bounds__(kThreads) void raster_backward_kernel(
     // Raw per-pixel inputs: the forward's saved aggregates and the incoming gradient.  They are
     // combined where they are used, so that the loads stay in flight across a step.
     // integers 2c + 1 - S of the box's first column and row (exact in fp32)
-    const float kx0 = (float)(2 * col0 + 1 - S), ky0 = (float)(2 * (S - 1 - row0) + 1 - S), fS = (float)S;
+    const float kx0 = (float)(2 * col0 + 1 - S), ky0 = (float)(2 * (S - 1 - row0) + 1 - S);
     struct PixIn {
         float xp, yp, xl, yl;
         float A, ssum, m, col[NC];          // saved: 1 - alpha product, softmax sum, max, colours
         float ga, gch[NC];                  // dL/d(alpha, colours) of the output pixel
         bool valid;
     };
-    const size_t plane = (size_t)H * H;
-    const bool only_alpha = MODE == SV3D_TEX_NONE && P.alpha_only;
-    // colour + alpha planes of image b, or its alpha plane alone
-    const float *grad_b = grad_rgba + (size_t)b * (only_alpha ? 1 : NC + 1) * plane;
-    const float *grad_alpha = grad_b + (only_alpha ? 0 : NC * plane);      // alpha plane of image b
     // per-pixel loads below take a wave-uniform base and a 32-bit byte offset (planes and the saved
     // array of one image stay far below 4 GB), which the hardware adds itself
     auto at32 = [](const float *base, unsigned index) -> float {
@@ -1382,6 +1457,7 @@ int make_dev_params(const sv3d_raster_params *p, DevParams &d)
     d.inv_S = (float)(1.0 / (double)p->raster_size);
     d.alpha_fast = (double)p->dist_eps / (1.0 - (double)p->dist_eps) < 2.9e-8;   // below half an ulp of 1
     d.alpha_only = p->alpha_only;
+    d.inv_F = p->num_faces == 1 ? 0xffffffffu : (unsigned)(0x100000000ull / (unsigned long long)p->num_faces);
     return SV3D_OK;
 }
 
