@@ -278,6 +278,11 @@ class Trainer(object):
             # of these passes are dropped, the weights do not move.  The last eager step's loss still
             # holds its autograd graph, whose gradient-accumulation nodes belong to the default stream.
             self.total_loss = None
+            # (the parameters' accumulation nodes were made on the default stream by the eager steps;
+            # torch warns about that once per pass on the side stream, and syncs as needed)
+            quiet = getattr(torch.autograd.graph, 'set_warn_on_accumulate_grad_stream_mismatch', None)
+            if quiet is not None:
+                quiet(False)
             side = torch.cuda.Stream(self.device)
             side.wait_stream(torch.cuda.current_stream(self.device))
             with torch.cuda.stream(side):
