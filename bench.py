@@ -76,7 +76,7 @@ class HipEvents:
 
     def __init__(self):
         self.hip = ctypes.CDLL("libamdhip64.so")
-        self.hip.hipEventCreate.argtypes = [ctypes.POINTER(ctypes.c_void_p)]
+        self.hip.hipEventCreateWithFlags.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_uint]
         self.hip.hipEventElapsedTime.argtypes = [ctypes.POINTER(ctypes.c_float), ctypes.c_void_p, ctypes.c_void_p]
         self.hip.hipEventDestroy.argtypes = [ctypes.c_void_p]
 
@@ -84,8 +84,11 @@ class HipEvents:
         out = []
         for _ in range(n):
             e = ctypes.c_void_p()
-            if self.hip.hipEventCreate(ctypes.byref(e)) != 0:
-                raise RuntimeError("hipEventCreate failed")
+            # hipEventDisableSystemFence: the events only time kernels on their own stream, they
+            # publish nothing to the host, and the system-scope fence of a default event adds
+            # microseconds of stream time to what it brackets
+            if self.hip.hipEventCreateWithFlags(ctypes.byref(e), int(os.environ.get("SV3D_EVENT_FLAGS", "0x20000000"), 0)) != 0:
+                raise RuntimeError("hipEventCreateWithFlags failed")
             out.append(e)
         return out
 
