@@ -9,6 +9,11 @@
 //   face_gather / face_scatter                 sr.Mesh's `vertices[faces]` + affine pre-stage
 //   project_gather / project_scatter           camera + flip + gather, nnutils/softras.py:58-61
 //   face_gather_n / face_scatter_n             per-vertex part maps (main.py:422-426) per face corner
+//   laplacian_loss / flatten_loss              sr.LaplacianLoss / sr.FlattenLoss (main.py:202-203,513,516):
+//                                              loss and vertex gradient in one launch
+//   mesh_spmv                                  CSR product of nnutils/laplacian.py:63-103
+//   texture_sample / texture_sample_backward   geom_utils.sample_textures (nnutils/geom_utils.py:11-26)
+//   distance_transform                         utils/image.py:94-113 on a batch of masks
 //
 // Every operator has a GPU kernel (key CUDA, which is HIP in a ROCm build of PyTorch), a Meta
 // kernel (shapes only: fake-tensor tracing) and, for the differentiable ones, an Autograd kernel.
@@ -523,6 +528,176 @@ std::tuple<Tensor, Tensor> project_scatter_meta(const Tensor &grad_out, const Te
     return {at::empty(vertices.sizes(), opt), at::empty(cams.sizes(), opt)};
 }
 
+// ---- mesh regularisers, CSR product, texture path ------------------------------------------------
+void check_vertices(const Tensor &v, const char *name)
+{
+    TORCH_CHECK_VALUE(v.dim() == 3 && v.size(2) == 3 && v.size(0) > 0 && v.size(1) > 0, name,
+                      " must be a non-empty [B,V,3] tensor, got ", v.sizes());
+    TORCH_CHECK_VALUE(v.is_floating_point(), name, " must be a floating point tensor");
+}
+
+void check_table(const Tensor &ref, const Tensor &t, const char *name)
+{
+    TORCH_CHECK_VALUE(t.scalar_type() == at::kInt && t.is_contiguous(), name, " must be a contiguous int32 tensor");
+    same_device(ref, t, name);      // a host table handed to a kernel is a GPU memory fault, not an exception
+}
+
+std::tuple<Tensor, Tensor> laplacian_loss_gpu(const Tensor &vertices, const Tensor &row_start, const Tensor &nbr)
+{
+    check_vertices(vertices, "vertices");
+    check_table(vertices, row_start, "row_start");
+    check_table(vertices, nbr, "nbr");
+    const Tensor x = f32c(vertices);
+    const int64_t B = x.size(0), V = x.size(1);
+    TORCH_CHECK_VALUE(row_start.numel() == V + 1, "row_start must hold V + 1 = ", V + 1, " entries, got ", row_start.numel());
+    Launch L(x);
+    Tensor loss = at::empty({B}, x.options()), grad = at::empty_like(x);
+    check_status(sv3d_laplacian_loss(x.data_ptr<float>(), row_start.data_ptr<int32_t>(), nbr.data_ptr<int32_t>(),
+                                     (int32_t)B, (int32_t)V, loss.data_ptr<float>(), grad.data_ptr<float>(), L.stream),
+                 "sv3d_laplacian_loss");
+    return {loss, grad};
+}
+
+std::tuple<Tensor, Tensor> loss_and_grad_meta(const Tensor &vertices)
+{
+    const auto opt = vertices.options().dtype(at::kFloat);
+    return {at::empty({vertices.size(0)}, opt), at::empty(vertices.sizes(), opt)};
+}
+
+std::tuple<Tensor, Tensor> laplacian_loss_meta(const Tensor &vertices, const Tensor &, const Tensor &)
+{
+    return loss_and_grad_meta(vertices);
+}
+
+std::tuple<Tensor, Tensor> flatten_loss_gpu(const Tensor &vertices, const Tensor &quads, const Tensor &inc_start,
+                                            const Tensor &inc, double eps)
+{
+    check_vertices(vertices, "vertices");
+    check_table(vertices, quads, "quads");
+    check_table(vertices, inc_start, "inc_start");
+    check_table(vertices, inc, "inc");
+    const Tensor x = f32c(vertices);
+    const int64_t B = x.size(0), V = x.size(1);
+    TORCH_CHECK_VALUE(quads.dim() == 2 && quads.size(1) == 4 && quads.size(0) > 0,
+                      "quads must be a non-empty [E,4] tensor, got ", quads.sizes());
+    const int64_t E = quads.size(0);
+    TORCH_CHECK_VALUE(inc_start.numel() == V + 1 && inc.numel() == 4 * E, "incidence tables must hold V + 1 and 4 E entries");
+    Launch L(x);
+    Tensor loss = at::empty({B}, x.options()), grad = at::empty_like(x);
+    check_status(sv3d_flatten_loss(x.data_ptr<float>(), quads.data_ptr<int32_t>(), inc_start.data_ptr<int32_t>(),
+                                   inc.data_ptr<int32_t>(), (int32_t)B, (int32_t)V, (int32_t)E, (float)eps,
+                                   loss.data_ptr<float>(), grad.data_ptr<float>(), L.stream),
+                 "sv3d_flatten_loss");
+    return {loss, grad};
+}
+
+std::tuple<Tensor, Tensor> flatten_loss_meta(const Tensor &vertices, const Tensor &, const Tensor &, const Tensor &, double)
+{
+    return loss_and_grad_meta(vertices);
+}
+
+// values_t, row_start_t, col_t: the transposed operator, used by the backward only
+Tensor mesh_spmv_gpu(const Tensor &x, const Tensor &values, const Tensor &row_start, const Tensor &col, const Tensor &,
+                     const Tensor &, const Tensor &)
+{
+    check_vertices(x, "x");
+    check_table(x, row_start, "row_start");
+    check_table(x, col, "col");
+    same_device(x, values, "values");
+    const Tensor xs = f32c(x), vals = f32c(values);
+    const int64_t B = xs.size(0), V = xs.size(1), nnz = col.numel();
+    TORCH_CHECK_VALUE(vals.dim() == 2 && vals.size(1) == nnz && (vals.size(0) == 1 || vals.size(0) == B),
+                      "values must be [B or 1, nnz=", nnz, "], got ", vals.sizes());
+    TORCH_CHECK_VALUE(row_start.numel() == V + 1, "row_start must hold V + 1 = ", V + 1, " entries, got ", row_start.numel());
+    Launch L(xs);
+    Tensor y = at::empty_like(xs);
+    check_status(sv3d_mesh_spmv(vals.data_ptr<float>(), row_start.data_ptr<int32_t>(), col.data_ptr<int32_t>(),
+                                xs.data_ptr<float>(), (int32_t)B, (int32_t)V, (int32_t)nnz, (int32_t)vals.size(0),
+                                y.data_ptr<float>(), L.stream),
+                 "sv3d_mesh_spmv");
+    return y;
+}
+
+Tensor mesh_spmv_meta(const Tensor &x, const Tensor &, const Tensor &, const Tensor &, const Tensor &, const Tensor &,
+                      const Tensor &)
+{
+    return at::empty(x.sizes(), x.options().dtype(at::kFloat));
+}
+
+constexpr int64_t kMaxSampleChannels = 4;
+
+void check_sample(const Tensor &images, const Tensor &flow)
+{
+    same_device(images, flow, "flow");
+    TORCH_CHECK_VALUE(images.dim() == 4 && images.size(1) >= 1 && images.size(1) <= kMaxSampleChannels &&
+                          images.size(2) >= 1 && images.size(3) >= 1,
+                      "images must be [B,C,H,W] with C <= ", kMaxSampleChannels, ", got ", images.sizes());
+    TORCH_CHECK_VALUE(flow.dim() == 3 && flow.size(2) == 2 && flow.size(0) == images.size(0) && flow.size(1) > 0,
+                      "flow must be [B,N,2] with the images' batch size, got ", flow.sizes());
+}
+
+Tensor texture_sample_gpu(const Tensor &images, const Tensor &flow)
+{
+    check_sample(images, flow);
+    const Tensor img = f32c(images), fl = f32c(flow);
+    const int64_t B = img.size(0), C = img.size(1), H = img.size(2), W = img.size(3), N = fl.size(1);
+    Launch L(img);
+    Tensor out = at::empty({B, N, C}, img.options());
+    check_status(sv3d_texture_sample(img.data_ptr<float>(), fl.data_ptr<float>(), (int32_t)B, (int32_t)C, (int32_t)H,
+                                     (int32_t)W, (int32_t)N, out.data_ptr<float>(), L.stream),
+                 "sv3d_texture_sample");
+    return out;
+}
+
+Tensor texture_sample_meta(const Tensor &images, const Tensor &flow)
+{
+    return at::empty({flow.size(0), flow.size(1), images.size(1)}, images.options().dtype(at::kFloat));
+}
+
+Tensor texture_sample_backward_gpu(const Tensor &images, const Tensor &flow, const Tensor &grad_out)
+{
+    check_sample(images, flow);
+    same_device(images, grad_out, "grad_out");
+    const Tensor img = f32c(images), fl = f32c(flow), g = f32c(grad_out);
+    const int64_t B = img.size(0), C = img.size(1), H = img.size(2), W = img.size(3), N = fl.size(1);
+    TORCH_CHECK_VALUE(g.dim() == 3 && g.size(0) == B && g.size(1) == N && g.size(2) == C, "grad_out must be [B,N,C], got ",
+                      g.sizes());
+    Launch L(img);
+    Tensor grad_flow = at::empty_like(fl);
+    check_status(sv3d_texture_sample_backward(img.data_ptr<float>(), fl.data_ptr<float>(), g.data_ptr<float>(), (int32_t)B,
+                                              (int32_t)C, (int32_t)H, (int32_t)W, (int32_t)N,
+                                              grad_flow.data_ptr<float>(), L.stream),
+                 "sv3d_texture_sample_backward");
+    return grad_flow;
+}
+
+Tensor texture_sample_backward_meta(const Tensor &, const Tensor &flow, const Tensor &)
+{
+    return at::empty(flow.sizes(), flow.options().dtype(at::kFloat));
+}
+
+Tensor distance_transform_gpu(const Tensor &masks, bool barrier, double k)
+{
+    TORCH_CHECK_VALUE(masks.dim() == 3 && masks.numel() > 0, "masks must be a non-empty [B,H,W] tensor, got ", masks.sizes());
+    const Tensor m = f32c(masks);
+    const int64_t B = m.size(0), H = m.size(1), W = m.size(2);
+    size_t bytes = 0;
+    check_status(sv3d_distance_transform_workspace((int32_t)B, (int32_t)H, (int32_t)W, &bytes),
+                 "sv3d_distance_transform_workspace");
+    Launch L(m);
+    Tensor out = at::empty_like(m);
+    Tensor ws = at::empty({(int64_t)bytes}, m.options().dtype(at::kByte));
+    check_status(sv3d_distance_transform(m.data_ptr<float>(), (int32_t)B, (int32_t)H, (int32_t)W, barrier ? 1 : 0, (float)k,
+                                         out.data_ptr<float>(), ws.data_ptr(), bytes, L.stream),
+                 "sv3d_distance_transform");
+    return out;
+}
+
+Tensor distance_transform_meta(const Tensor &masks, bool, double)
+{
+    return at::empty(masks.sizes(), masks.options().dtype(at::kFloat));
+}
+
 // ---- dispatcher handles (calls from the autograd kernels go below autograd) ----------------------
 template <class Sig>
 c10::TypedOperatorHandle<Sig> find_op(const char *name)
@@ -769,6 +944,119 @@ Tensor project_gather_autograd(const Tensor &v, const Tensor &c, const Tensor &f
     return ProjectGatherFn::apply(v, c, f, mesh_cfg);
 }
 
+
+// loss [B] with its vertex gradient computed by the same launch: the backward scales that gradient
+template <class Derived>
+struct LossWithGradFn : public torch::autograd::Function<Derived> {
+    static variable_list backward(AutogradContext *ctx, variable_list grads)
+    {
+        variable_list out(Derived::kInputs);
+        if (!grads[0].defined()) return out;
+        const auto saved = ctx->get_saved_variables();
+        const Tensor g = grads[0].to(at::kFloat).view({-1, 1, 1}) * saved[0];
+        out[0] = cast_like(g, (at::ScalarType)ctx->saved_data["dtype"].toInt());
+        return out;
+    }
+};
+
+struct LaplacianLossFn : public LossWithGradFn<LaplacianLossFn> {
+    static constexpr int kInputs = 3;
+    static variable_list forward(AutogradContext *ctx, const Tensor &v, const Tensor &row_start, const Tensor &nbr)
+    {
+        at::AutoDispatchBelowADInplaceOrView guard;
+        static auto op = find_op<std::tuple<Tensor, Tensor>(const Tensor &, const Tensor &, const Tensor &)>("sv3d::laplacian_loss");
+        auto out = op.call(v, row_start, nbr);
+        ctx->save_for_backward({std::get<1>(out)});
+        ctx->saved_data["dtype"] = (int64_t)v.scalar_type();
+        ctx->mark_non_differentiable({std::get<1>(out)});
+        ctx->set_materialize_grads(false);
+        return {std::get<0>(out), std::get<1>(out)};
+    }
+};
+
+std::tuple<Tensor, Tensor> laplacian_loss_autograd(const Tensor &v, const Tensor &row_start, const Tensor &nbr)
+{
+    auto out = LaplacianLossFn::apply(v, row_start, nbr);
+    return {out[0], out[1]};
+}
+
+struct FlattenLossFn : public LossWithGradFn<FlattenLossFn> {
+    static constexpr int kInputs = 5;
+    static variable_list forward(AutogradContext *ctx, const Tensor &v, const Tensor &quads, const Tensor &inc_start,
+                                 const Tensor &inc, double eps)
+    {
+        at::AutoDispatchBelowADInplaceOrView guard;
+        static auto op = find_op<std::tuple<Tensor, Tensor>(const Tensor &, const Tensor &, const Tensor &, const Tensor &,
+                                                            double)>("sv3d::flatten_loss");
+        auto out = op.call(v, quads, inc_start, inc, eps);
+        ctx->save_for_backward({std::get<1>(out)});
+        ctx->saved_data["dtype"] = (int64_t)v.scalar_type();
+        ctx->mark_non_differentiable({std::get<1>(out)});
+        ctx->set_materialize_grads(false);
+        return {std::get<0>(out), std::get<1>(out)};
+    }
+};
+
+std::tuple<Tensor, Tensor> flatten_loss_autograd(const Tensor &v, const Tensor &quads, const Tensor &inc_start,
+                                                 const Tensor &inc, double eps)
+{
+    auto out = FlattenLossFn::apply(v, quads, inc_start, inc, eps);
+    return {out[0], out[1]};
+}
+
+using SpmvSig = Tensor(const Tensor &, const Tensor &, const Tensor &, const Tensor &, const Tensor &, const Tensor &,
+                       const Tensor &);
+
+struct MeshSpmvFn : public torch::autograd::Function<MeshSpmvFn> {
+    static Tensor forward(AutogradContext *ctx, const Tensor &x, const Tensor &values, const Tensor &row_start,
+                          const Tensor &col, const Tensor &values_t, const Tensor &row_start_t, const Tensor &col_t)
+    {
+        at::AutoDispatchBelowADInplaceOrView guard;
+        static auto op = find_op<SpmvSig>("sv3d::mesh_spmv");
+        ctx->save_for_backward({values, row_start, col, values_t, row_start_t, col_t});
+        ctx->saved_data["dtype"] = (int64_t)x.scalar_type();
+        return op.call(x, values, row_start, col, values_t, row_start_t, col_t);
+    }
+
+    static variable_list backward(AutogradContext *ctx, variable_list grads)
+    {
+        static auto op = find_op<SpmvSig>("sv3d::mesh_spmv");
+        const auto s = ctx->get_saved_variables();
+        // x -> A x is linear: the gradient is the transposed operator applied to the incoming one
+        // (through the dispatcher, so that it is differentiable in turn)
+        Tensor g = op.call(grads[0], s[3], s[4], s[5], s[0], s[1], s[2]);
+        return {cast_like(g, (at::ScalarType)ctx->saved_data["dtype"].toInt()), Tensor(), Tensor(), Tensor(), Tensor(),
+                Tensor(), Tensor()};
+    }
+};
+
+Tensor mesh_spmv_autograd(const Tensor &x, const Tensor &values, const Tensor &row_start, const Tensor &col,
+                          const Tensor &values_t, const Tensor &row_start_t, const Tensor &col_t)
+{
+    return MeshSpmvFn::apply(x, values, row_start, col, values_t, row_start_t, col_t);
+}
+
+struct TextureSampleFn : public torch::autograd::Function<TextureSampleFn> {
+    static Tensor forward(AutogradContext *ctx, const Tensor &images, const Tensor &flow)
+    {
+        TORCH_CHECK(!images.requires_grad(), "sv3d::texture_sample has no gradient for the images");
+        at::AutoDispatchBelowADInplaceOrView guard;
+        static auto op = find_op<Tensor(const Tensor &, const Tensor &)>("sv3d::texture_sample");
+        ctx->save_for_backward({images, flow});
+        return op.call(images, flow);
+    }
+
+    static variable_list backward(AutogradContext *ctx, variable_list grads)
+    {
+        static auto op = find_op<Tensor(const Tensor &, const Tensor &, const Tensor &)>("sv3d::texture_sample_backward");
+        const auto s = ctx->get_saved_variables();
+        Tensor g = op.call(s[0], s[1], grads[0]);
+        return {Tensor(), cast_like(g, s[1].scalar_type())};
+    }
+};
+
+Tensor texture_sample_autograd(const Tensor &images, const Tensor &flow) { return TextureSampleFn::apply(images, flow); }
+
 }  // namespace
 
 TORCH_LIBRARY(sv3d, m)
@@ -790,6 +1078,13 @@ TORCH_LIBRARY(sv3d, m)
     m.def("face_scatter_n(Tensor grad_out, Tensor faces, int num_vertices) -> Tensor");
     m.def("project_gather(Tensor vertices, Tensor cams, Tensor faces, float[] mesh_cfg) -> Tensor");
     m.def("project_scatter(Tensor grad_out, Tensor vertices, Tensor cams, Tensor faces, float[] mesh_cfg) -> (Tensor, Tensor)");
+    m.def("laplacian_loss(Tensor vertices, Tensor row_start, Tensor nbr) -> (Tensor, Tensor)");
+    m.def("flatten_loss(Tensor vertices, Tensor quads, Tensor inc_start, Tensor inc, float eps) -> (Tensor, Tensor)");
+    m.def("mesh_spmv(Tensor x, Tensor values, Tensor row_start, Tensor col, Tensor values_t, Tensor row_start_t, "
+          "Tensor col_t) -> Tensor");
+    m.def("texture_sample(Tensor images, Tensor flow) -> Tensor");
+    m.def("texture_sample_backward(Tensor images, Tensor flow, Tensor grad_out) -> Tensor");
+    m.def("distance_transform(Tensor masks, bool barrier, float k) -> Tensor");
 }
 
 TORCH_LIBRARY_IMPL(sv3d, CUDA, m)
@@ -806,6 +1101,12 @@ TORCH_LIBRARY_IMPL(sv3d, CUDA, m)
     m.impl("face_scatter_n", face_scatter_n_gpu);
     m.impl("project_gather", project_gather_gpu);
     m.impl("project_scatter", project_scatter_gpu);
+    m.impl("laplacian_loss", laplacian_loss_gpu);
+    m.impl("flatten_loss", flatten_loss_gpu);
+    m.impl("mesh_spmv", mesh_spmv_gpu);
+    m.impl("texture_sample", texture_sample_gpu);
+    m.impl("texture_sample_backward", texture_sample_backward_gpu);
+    m.impl("distance_transform", distance_transform_gpu);
 }
 
 TORCH_LIBRARY_IMPL(sv3d, Meta, m)
@@ -822,6 +1123,12 @@ TORCH_LIBRARY_IMPL(sv3d, Meta, m)
     m.impl("face_scatter_n", face_scatter_n_meta);
     m.impl("project_gather", project_gather_meta);
     m.impl("project_scatter", project_scatter_meta);
+    m.impl("laplacian_loss", laplacian_loss_meta);
+    m.impl("flatten_loss", flatten_loss_meta);
+    m.impl("mesh_spmv", mesh_spmv_meta);
+    m.impl("texture_sample", texture_sample_meta);
+    m.impl("texture_sample_backward", texture_sample_backward_meta);
+    m.impl("distance_transform", distance_transform_meta);
 }
 
 TORCH_LIBRARY_IMPL(sv3d, Autograd, m)
@@ -832,4 +1139,8 @@ TORCH_LIBRARY_IMPL(sv3d, Autograd, m)
     m.impl("face_gather", face_gather_autograd);
     m.impl("face_gather_n", face_gather_n_autograd);
     m.impl("project_gather", project_gather_autograd);
+    m.impl("laplacian_loss", laplacian_loss_autograd);
+    m.impl("flatten_loss", flatten_loss_autograd);
+    m.impl("mesh_spmv", mesh_spmv_autograd);
+    m.impl("texture_sample", texture_sample_autograd);
 }

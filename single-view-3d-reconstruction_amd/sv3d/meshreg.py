@@ -1,16 +1,15 @@
-"""Mesh regularisers on the device: torch custom ops over `sv3d_laplacian_loss`,
-`sv3d_flatten_loss` and `sv3d_mesh_spmv` (include/sv3d_hip.h), and the host-side index tables
-they read (built once per topology with numpy).
+"""Mesh regularisers on the device: entry points of the operators `sv3d::laplacian_loss`,
+`sv3d::flatten_loss` and `sv3d::mesh_spmv` (csrc/torch_ops.cpp over `sv3d_laplacian_loss`,
+`sv3d_flatten_loss`, `sv3d_mesh_spmv` of include/sv3d_hip.h), and the host-side index tables they
+read (built once per topology with numpy).
 
-The two loss ops return `(loss [B], dloss/dvertices [B,V,3])` from one launch; autograd only
-scales the second output.  There is no CPU implementation: CPU tensors raise.
+The two loss operators return `(loss [B], dloss/dvertices [B,V,3])` from one launch; autograd only
+scales the second output.  There is no CPU implementation: CPU tensors fail in the dispatcher.
 """
 import numpy as np
 import torch
-from torch import Tensor
 
-from . import _lib as L
-from .ops import _f32c, _on, _plain, _ptr, _stream
+from .ops import _ops
 
 
 # ----------------------------------------------------------------------------------------------
@@ -84,178 +83,19 @@ def csr_from_coo(rows, cols, num_rows):
 
 
 # ----------------------------------------------------------------------------------------------
-# ops
-def _check_vertices(x):
-    if not x.is_cuda:
-        raise RuntimeError("sv3d mesh regularisers run on the GPU only (got a %s tensor)" % x.device.type)
-    if x.dim() != 3 or x.shape[2] != 3 or x.shape[0] == 0 or x.shape[1] == 0:
-        raise ValueError("vertices must be a non-empty [B,V,3] tensor, got %s" % (tuple(x.shape),))
-
-
-def _check_i32(t, name, like=None):
-    if t.dtype != torch.int32 or not t.is_contiguous():
-        raise ValueError("%s must be a contiguous int32 tensor" % name)
-    if like is not None and t.device != like.device:
-        # a host pointer handed to a kernel is a GPU memory fault, not an exception: refuse it here
-        raise RuntimeError("%s is on %s but the vertices are on %s (move the loss module to the GPU)"
-                           % (name, t.device, like.device))
-
-
-def _laplacian_launch(vertices, row_start, nbr):
-    _check_vertices(vertices)
-    _check_i32(row_start, "row_start", vertices)
-    _check_i32(nbr, "nbr", vertices)
-    x = _f32c(vertices)
-    B, V = x.shape[0], x.shape[1]
-    if row_start.numel() != V + 1:
-        raise ValueError("row_start must hold V + 1 = %d entries, got %d" % (V + 1, row_start.numel()))
-    with _on(x.device):
-        loss = torch.empty((B,), dtype=torch.float32, device=x.device)
-        grad = torch.empty_like(x)
-        L.check(L.lib().sv3d_laplacian_loss(_ptr(x), _ptr(row_start), _ptr(nbr), B, V, _ptr(loss), _ptr(grad),
-                                            _stream(x)), "sv3d_laplacian_loss")
-    return loss, grad
-
-
-@torch.library.custom_op("sv3d::laplacian_loss", mutates_args=(), device_types="cuda")
-def laplacian_loss_op(vertices: Tensor, row_start: Tensor, nbr: Tensor) -> tuple[Tensor, Tensor]:
-    return _laplacian_launch(vertices, row_start, nbr)
-
-
-@laplacian_loss_op.register_fake
-def _(vertices, row_start, nbr):
-    return (vertices.new_empty((vertices.shape[0],), dtype=torch.float32),
-            vertices.new_empty(vertices.shape, dtype=torch.float32))
-
-
-def _flatten_launch(vertices, quads, inc_start, inc, eps):
-    _check_vertices(vertices)
-    for t, name in ((quads, "quads"), (inc_start, "inc_start"), (inc, "inc")):
-        _check_i32(t, name, vertices)
-    x = _f32c(vertices)
-    B, V, E = x.shape[0], x.shape[1], quads.shape[0]
-    if quads.dim() != 2 or quads.shape[1] != 4 or E == 0:
-        raise ValueError("quads must be a non-empty [E,4] tensor, got %s" % (tuple(quads.shape),))
-    if inc_start.numel() != V + 1 or inc.numel() != 4 * E:
-        raise ValueError("incidence tables must hold V + 1 and 4 E entries")
-    with _on(x.device):
-        loss = torch.empty((B,), dtype=torch.float32, device=x.device)
-        grad = torch.empty_like(x)
-        L.check(L.lib().sv3d_flatten_loss(_ptr(x), _ptr(quads), _ptr(inc_start), _ptr(inc), B, V, E, float(eps),
-                                          _ptr(loss), _ptr(grad), _stream(x)), "sv3d_flatten_loss")
-    return loss, grad
-
-
-@torch.library.custom_op("sv3d::flatten_loss", mutates_args=(), device_types="cuda")
-def flatten_loss_op(vertices: Tensor, quads: Tensor, inc_start: Tensor, inc: Tensor,
-                    eps: float) -> tuple[Tensor, Tensor]:
-    return _flatten_launch(vertices, quads, inc_start, inc, eps)
-
-
-@flatten_loss_op.register_fake
-def _(vertices, quads, inc_start, inc, eps):
-    return (vertices.new_empty((vertices.shape[0],), dtype=torch.float32),
-            vertices.new_empty(vertices.shape, dtype=torch.float32))
-
-
-def _loss_setup_context(ctx, inputs, output):
-    ctx.save_for_backward(output[1])
-    ctx.dtype = inputs[0].dtype
-    ctx.set_materialize_grads(False)
-
-
-def _laplacian_backward(ctx, grad_loss, _grad_of_grad):
-    (g,) = ctx.saved_tensors
-    if grad_loss is None:
-        return None, None, None
-    return (grad_loss.to(torch.float32)[:, None, None] * g).to(ctx.dtype), None, None
-
-
-def _flatten_backward(ctx, grad_loss, _grad_of_grad):
-    (g,) = ctx.saved_tensors
-    if grad_loss is None:
-        return None, None, None, None, None
-    return (grad_loss.to(torch.float32)[:, None, None] * g).to(ctx.dtype), None, None, None, None
-
-
-laplacian_loss_op.register_autograd(_laplacian_backward, setup_context=_loss_setup_context)
-flatten_loss_op.register_autograd(_flatten_backward, setup_context=_loss_setup_context)
-
-
-@torch.library.custom_op("sv3d::mesh_spmv", mutates_args=(), device_types="cuda")
-def mesh_spmv_op(x: Tensor, values: Tensor, row_start: Tensor, col: Tensor,
-                 values_t: Tensor, row_start_t: Tensor, col_t: Tensor) -> Tensor:
-    _check_vertices(x)
-    _check_i32(row_start, "row_start", x)
-    _check_i32(col, "col", x)
-    if values.device != x.device:
-        raise RuntimeError("values are on %s but x is on %s" % (values.device, x.device))
-    xs, vals = _f32c(x), _f32c(values)
-    B, V, nnz = xs.shape[0], xs.shape[1], col.numel()
-    if vals.dim() != 2 or vals.shape[1] != nnz or vals.shape[0] not in (1, B):
-        raise ValueError("values must be [B or 1, nnz=%d], got %s" % (nnz, tuple(vals.shape)))
-    if row_start.numel() != V + 1:
-        raise ValueError("row_start must hold V + 1 = %d entries, got %d" % (V + 1, row_start.numel()))
-    with _on(xs.device):
-        y = torch.empty_like(xs)
-        L.check(L.lib().sv3d_mesh_spmv(_ptr(vals), _ptr(row_start), _ptr(col), _ptr(xs), B, V, nnz, vals.shape[0],
-                                       _ptr(y), _stream(xs)), "sv3d_mesh_spmv")
-    return y
-
-
-@mesh_spmv_op.register_fake
-def _(x, values, row_start, col, values_t, row_start_t, col_t):
-    return x.new_empty(x.shape, dtype=torch.float32)
-
-
-def _spmv_setup_context(ctx, inputs, output):
-    x, values, row_start, col, values_t, row_start_t, col_t = inputs
-    ctx.save_for_backward(values, row_start, col, values_t, row_start_t, col_t)
-    ctx.dtype = x.dtype
-
-
-def _spmv_backward(ctx, grad_y):
-    values, row_start, col, values_t, row_start_t, col_t = ctx.saved_tensors
-    gx = mesh_spmv_op(grad_y, values_t, row_start_t, col_t, values, row_start, col)
-    return gx.to(ctx.dtype), None, None, None, None, None, None
-
-
-mesh_spmv_op.register_autograd(_spmv_backward, setup_context=_spmv_setup_context)
-
-
-class _FusedLossFn(torch.autograd.Function):
-    """Eager path of the two loss ops without the custom-op dispatcher (which costs more host time
-    than the kernels take): `op` is the op's own python body."""
-
-    @staticmethod
-    def forward(ctx, vertices, op, *tables):
-        loss, grad = op(vertices, *tables)
-        ctx.save_for_backward(grad)
-        ctx.dtype, ctx.n = vertices.dtype, len(tables)
-        return loss
-
-    @staticmethod
-    def backward(ctx, grad_loss):
-        (g,) = ctx.saved_tensors
-        return ((grad_loss.to(torch.float32)[:, None, None] * g).to(ctx.dtype), None) + (None,) * ctx.n
-
-
+# operators
 def laplacian_loss(vertices, row_start, nbr):
     """loss [B] = sum_v |x_v - mean(neighbours)|^2 for neighbour lists from `neighbour_csr`."""
-    if _plain(vertices, row_start, nbr):
-        return _FusedLossFn.apply(vertices, _laplacian_launch, row_start, nbr)
-    return laplacian_loss_op(vertices, row_start, nbr)[0]
+    return _ops.laplacian_loss(vertices, row_start, nbr)[0]
 
 
 def flatten_loss(vertices, quads, inc_start, inc, eps=1e-6):
     """loss [B] = sum over the edges of `edge_quads` of (cos + 1)^2."""
-    if _plain(vertices, quads, inc_start, inc):
-        return _FusedLossFn.apply(vertices, _flatten_launch, quads, inc_start, inc, eps)
-    return flatten_loss_op(vertices, quads, inc_start, inc, eps)[0]
+    return _ops.flatten_loss(vertices, quads, inc_start, inc, float(eps))[0]
 
 
 def mesh_spmv(x, csr, csr_t=None):
     """y = A x for A = (values [B or 1, nnz], row_start, col); `csr_t` is A's transpose in the same
     form (used by the backward), A itself when omitted (symmetric operators)."""
     csr_t = csr if csr_t is None else csr_t
-    return mesh_spmv_op(x, csr[0], csr[1], csr[2], csr_t[0], csr_t[1], csr_t[2])
+    return _ops.mesh_spmv(x, csr[0], csr[1], csr[2], csr_t[0], csr_t[1], csr_t[2])

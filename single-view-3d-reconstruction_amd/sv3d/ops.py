@@ -14,14 +14,12 @@ arguments.  All operators are GPU-only -- a CPU tensor fails in the dispatcher, 
                                              the object-space mesh (camera folded into setup)
   face_gather_n / face_scatter_n             per-vertex part maps gathered per face corner
 
-The helpers at the top (`_ptr`, `_stream`, `_f32c`, `_on`, `_plain`) serve the ctypes-bound
-operators of `sv3d.meshreg` and `sv3d.texture`.
+The mesh regularisers, the CSR product, texture sampling and the distance transforms are operators
+of the same library; their entry points are in `sv3d.meshreg` and `sv3d.texture`.
 """
-import ctypes
 import os
 
 import torch
-from torch import Tensor
 
 from . import _lib as L
 
@@ -39,55 +37,6 @@ def _load_torch_ops():
 
 
 _ops = _load_torch_ops()
-
-
-# ---- helpers of the ctypes-bound operators (sv3d.meshreg, sv3d.texture) ------------------------
-def _ptr(t):
-    return ctypes.c_void_p(t.data_ptr()) if t is not None and t.numel() > 0 else None
-
-
-_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
-
-
-def _stream(t):
-    """The current stream of the tensor's device as a raw handle."""
-    if _raw_stream is not None:
-        return ctypes.c_void_p(_raw_stream(t.device.index))
-    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
-
-
-def _f32c(t):
-    """Detached fp32 contiguous view (a copy only when the tensor is not that already)."""
-    t = t.detach()
-    if t.dtype is not torch.float32:
-        t = t.to(torch.float32)
-    return t if t.is_contiguous() else t.contiguous()
-
-
-class _NoGuard:
-    def __enter__(self):
-        return None
-
-    def __exit__(self, *exc):
-        return False
-
-
-_NO_GUARD = _NoGuard()
-
-
-def _on(device):
-    """Device guard for allocations and launches; free when `device` is the current one."""
-    return _NO_GUARD if device.index == torch.cuda.current_device() else torch.cuda.device(device)
-
-
-def _plain(*tensors):
-    """True when every tensor is an ordinary eager tensor (no fake / functional wrapper)."""
-    if torch.compiler.is_compiling():
-        return False
-    for t in tensors:
-        if t is not None and type(t) is not Tensor and type(t) is not torch.nn.Parameter:
-            return False
-    return True
 
 
 # ---- argument packing --------------------------------------------------------------------------

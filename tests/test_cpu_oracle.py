@@ -239,7 +239,8 @@ def test_torch_operator_library_registers_every_operator():
     import sv3d  # noqa: F401  (loads both libraries)
     names = ("soft_rasterize", "soft_rasterize_backward", "render", "render_backward", "chamfer_nn",
              "chamfer_nn_backward", "face_gather", "face_scatter", "face_gather_n", "face_scatter_n",
-             "project_gather", "project_scatter")
+             "project_gather", "project_scatter", "laplacian_loss", "flatten_loss", "mesh_spmv", "texture_sample",
+             "texture_sample_backward", "distance_transform")
     for n in names:
         assert hasattr(torch.ops.sv3d, n), n
     meta = dict(device="meta")
@@ -250,5 +251,15 @@ def test_torch_operator_library_registers_every_operator():
     assert rgba.shape == (3, 4, 256, 256) and saved.numel() == 3 * 512 * 512
     d1, d2, i1, i2 = torch.ops.sv3d.chamfer_nn(torch.empty(2, 10, 3, **meta), torch.empty(2, 20, 3, **meta))
     assert d2.shape == (2, 20) and i1.dtype == torch.int32
+    loss, grad = torch.ops.sv3d.flatten_loss(v, torch.empty(410, 4, dtype=torch.int32, **meta),
+                                             torch.empty(643, dtype=torch.int32, **meta),
+                                             torch.empty(1640, dtype=torch.int32, **meta), 1e-6)
+    assert loss.shape == (3,) and grad.shape == v.shape
+    tex = torch.ops.sv3d.texture_sample(torch.empty(3, 3, 64, 64, **meta), torch.empty(3, 1280 * 36, 2, **meta))
+    assert tex.shape == (3, 1280 * 36, 3)
+    assert torch.ops.sv3d.distance_transform(torch.empty(3, 64, 48, **meta), True, 50.0).shape == (3, 64, 48)
     with pytest.raises(NotImplementedError):
         torch.ops.sv3d.chamfer_nn(torch.zeros(1, 3, 3), torch.zeros(1, 4, 3))
+    with pytest.raises(NotImplementedError):
+        torch.ops.sv3d.laplacian_loss(torch.zeros(1, 3, 3), torch.zeros(4, dtype=torch.int32),
+                                      torch.zeros(6, dtype=torch.int32))

@@ -263,6 +263,6 @@ def test_regulariser_ops_trace_under_fake_tensors():
     rs, nb = meshreg.neighbour_csr(faces, 642)
     with FakeTensorMode():
         x = torch.empty(2, 642, 3, device="cuda")
-        loss, grad = meshreg.laplacian_loss_op(x, torch.empty(643, dtype=torch.int32, device="cuda"),
+        loss, grad = torch.ops.sv3d.laplacian_loss(x, torch.empty(643, dtype=torch.int32, device="cuda"),
                                                torch.empty(nb.size, dtype=torch.int32, device="cuda"))
         assert loss.shape == (2,) and grad.shape == (2, 642, 3)

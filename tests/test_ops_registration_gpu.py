@@ -81,15 +81,15 @@ def test_opcheck_regulariser_and_texture_ops():
     V = verts.shape[0]
     x = random_vertices(verts, 2, 3).cuda().requires_grad_(True)
     rs, nb = (torch.from_numpy(a).cuda() for a in meshreg.neighbour_csr(faces, V))
-    torch.library.opcheck(meshreg.laplacian_loss_op, (x, rs, nb), test_utils=TESTS)
+    torch.library.opcheck(torch.ops.sv3d.laplacian_loss.default, (x, rs, nb), test_utils=TESTS)
     q = meshreg.edge_quads(faces)
     inc_start, inc = (torch.from_numpy(a).cuda() for a in meshreg.incidence_csr(q, V))
     quads = torch.from_numpy(q).int().cuda()
-    torch.library.opcheck(meshreg.flatten_loss_op, (x, quads, inc_start, inc, 1e-6), test_utils=TESTS)
+    torch.library.opcheck(torch.ops.sv3d.flatten_loss.default, (x, quads, inc_start, inc, 1e-6), test_utils=TESTS)
     vals = torch.rand(1, nb.numel(), device="cuda")
-    torch.library.opcheck(meshreg.mesh_spmv_op, (x, vals, rs, nb, vals, rs, nb), test_utils=TESTS)
+    torch.library.opcheck(torch.ops.sv3d.mesh_spmv.default, (x, vals, rs, nb, vals, rs, nb), test_utils=TESTS)
     images = torch.rand(2, 3, 16, 16, device="cuda")
     flow = (2 * torch.rand(2, 40, 2, device="cuda") - 1).requires_grad_(True)
-    torch.library.opcheck(texture.texture_sample_op, (images, flow), test_utils=TESTS)
+    torch.library.opcheck(torch.ops.sv3d.texture_sample.default, (images, flow), test_utils=TESTS)
     masks = (torch.rand(2, 24, 40, device="cuda") < 0.3).float()
-    torch.library.opcheck(texture.distance_transform_op, (masks, True, 50.0), test_utils=TESTS)
+    torch.library.opcheck(torch.ops.sv3d.distance_transform.default, (masks, True, 50.0), test_utils=TESTS)
