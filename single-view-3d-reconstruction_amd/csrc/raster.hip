@@ -142,38 +142,24 @@ __device__ inline FaceRec load_rec(const float4 *r)
     return o;
 }
 
-// The record of a wave-uniform face through the scalar cache: all 128 bytes requested at once
-// (rec_request), waited for once (rec_wait), with whatever does not need the record placed between
-// the two calls.  (Written as loads of the record's float4s the compiler splits them into three
-// batches near their uses with a wait after each; scalar loads return in any order, so every wait
-// is for everything outstanding, and the batches become trips to memory in a row.)  Between the
-// two calls the four register blocks must not be touched: their values are not there yet.
-typedef float rec_f8 __attribute__((ext_vector_type(8)));
-struct RecRegs {
-    rec_f8 a, b, c, d;
-};
-
-__device__ inline void rec_request(const float4 *r, RecRegs &q)
+// The record of a wave-uniform face through the scalar cache, all 128 bytes requested at once and
+// waited for once, in one statement.  (Written as loads of the record's float4s the compiler splits
+// them into three batches near their uses with a wait after each; scalar loads return in any order,
+// so every wait is for everything outstanding, and the batches become trips to memory in a row.
+// Request and wait are not split into two statements with work between them: nothing could stop
+// the register allocator from copying a register block that the load has not written yet.)
+__device__ inline FaceRec load_rec_uniform(const float4 *r)
 {
+    typedef float f8 __attribute__((ext_vector_type(8)));
+    f8 a, b, c, d;
     asm volatile("s_load_dwordx8 %0, %4, 0x0\n\t"
                  "s_load_dwordx8 %1, %4, 0x20\n\t"
                  "s_load_dwordx8 %2, %4, 0x40\n\t"
-                 "s_load_dwordx8 %3, %4, 0x60"
-                 : "=&s"(q.a), "=&s"(q.b), "=&s"(q.c), "=&s"(q.d)
+                 "s_load_dwordx8 %3, %4, 0x60\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&s"(a), "=&s"(b), "=&s"(c), "=&s"(d)
                  : "s"(r)
                  : "memory");
-}
-
-__device__ inline FaceRec rec_wait(RecRegs &q, const void *done0, const void *done1, const void *done2)
-{
-    // The blocks are operands of the wait, so that no use of them can be placed ahead of it; the
-    // `done` values are results of the work meant to overlap the load: as inputs of the wait they
-    // are computed before it.
-    asm volatile("s_waitcnt lgkmcnt(0)"
-                 : "+s"(q.a), "+s"(q.b), "+s"(q.c), "+s"(q.d)
-                 : "s"(done0), "s"(done1), "s"(done2)
-                 : "memory");
-    const rec_f8 a = q.a, b = q.b, c = q.c, d = q.d;
     FaceRec o;
     o.p0x = a[0]; o.p0y = a[1]; o.p1x = a[2]; o.p1y = a[3];
     o.p2x = a[4]; o.p2y = a[5]; o.e0x = a[6]; o.e0y = a[7];
@@ -1074,8 +1060,7 @@ __global__ __launch_bounds__(kThreads) void raster_backward_kernel(
     const bool live = gf_raw < P.B * P.F;
     if (HALVES == 1 && !live) return;           // whole wave; HALVES == 1 uses no block-level barrier
     const int gf = live ? gf_raw : P.B * P.F - 1;       // HALVES == 2: idle waves still reach the barrier
-    // Every kernel argument the wave will read is brought into registers first: a scalar load for
-    // one of them between the record's request and its wait would make that wait come early.
+    // Every kernel argument the wave will read is brought into registers in one batch first.
     // (Not in the eight-channel mode, whose registers leave no room for either: measured +7 % there.)
     constexpr bool kRequestAhead = MODE != SV3D_TEX_VERTEX8;
     if (kRequestAhead)
@@ -1084,9 +1069,6 @@ __global__ __launch_bounds__(kThreads) void raster_backward_kernel(
                      "s"(tex));
     // The pixel box is taken from the record (floats 28..29), not from the compact box array: one
     // request, one wait, then the pixel loads can go out.
-    RecRegs rec_regs;
-    if (kRequestAhead) rec_request(rec + (size_t)gf * kRec4, rec_regs);
-    // ---- nothing from here to rec_wait needs the record ----
     const int b = image_of_face(gf, P.F, P.inv_F);
     const int tgf = P.TB == P.B ? gf : gf - (b - b % P.TB) * P.F;     // the face in its texture set
     const int S = P.S;
@@ -1102,7 +1084,7 @@ __global__ __launch_bounds__(kThreads) void raster_backward_kernel(
     const float *grad_b = grad_rgba + (size_t)b * (only_alpha ? 1 : NC + 1) * plane;
     const float *grad_alpha = grad_b + (only_alpha ? 0 : NC * plane);      // alpha plane of image b
     const float fS = (float)S;
-    const FaceRec r = kRequestAhead ? rec_wait(rec_regs, saved_b, grad_b, grad_alpha) : load_rec(rec + (size_t)gf * kRec4);
+    const FaceRec r = kRequestAhead ? load_rec_uniform(rec + (size_t)gf * kRec4) : load_rec(rec + (size_t)gf * kRec4);
     int col0, col1, row0, row1;
     unpack_box(make_uint2(r.box_x, r.box_y), col0, col1, row0, row1);
     const int bw = col1 - col0 + 1, bh = row1 - row0 + 1;
