@@ -314,7 +314,7 @@ def chamfer_leg(device):
 
 def train_step_leg(args, device, world, rank):
     """examples/cmr_synthetic.py's step (encoder, camera hypotheses, shared render passes, part maps,
-    Chamfer, regularisers, distance-map loss, autocast + clip + Adam x2) at batch 4 per rank."""
+    Chamfer, regularisers, distance-map loss, autocast + clip + fused Adam x2) at batch 4 per rank."""
     import tempfile
     cmr = _load_cmr_module()
     tmp = tempfile.mkdtemp(prefix="sv3d_bench_")
@@ -345,24 +345,29 @@ def train_step_leg(args, device, world, rank):
     per_rank = steps * o.batch_size / dt
     graphed = None
     if world == 1:
-        # the same step with forward + loss + backward replayed from a HIP graph (one process only:
-        # the eager figure above is the one that is comparable across rank counts)
-        o.cuda_graph = 1
-        o.num_iter = 4                               # capture, then a few replays
-        t.train()
-        o.num_iter = args.train_steps
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        gsteps = t.train()
-        torch.cuda.synchronize()
-        gdt = time.perf_counter() - t0
+        # the same step replayed from a HIP graph (one process only: the eager figure above is the
+        # one that is comparable across rank counts).  Mode 1 holds forward + loss + backward, mode 2
+        # the optimizer steps as well.
+        def replayed(mode):
+            o.cuda_graph = mode
+            o.num_iter = 4                           # capture, then a few replays
+            t.train()
+            o.num_iter = args.train_steps
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            gsteps = t.train()
+            torch.cuda.synchronize()
+            return gsteps, time.perf_counter() - t0
+        s1, d1 = replayed(1)
+        gsteps, gdt = replayed(2)
         graphed = {"ms_per_step": 1e3 * gdt / gsteps, "dataset_images_per_s": gsteps * o.batch_size / gdt,
-                   "what": "--cuda_graph 1: forward + loss + backward captured once in a HIP graph and replayed; "
-                           "unscale, clipping and the two Adam steps eager"}
+                   "what": "--cuda_graph 2: forward + loss + backward + unscale + clipping + the two fused Adam "
+                           "steps + scaler update captured once in a HIP graph and replayed",
+                   "forward_backward_only_ms_per_step": 1e3 * d1 / s1}
     return {"what": "synthetic CMR-style training step (examples/cmr_synthetic.py): ResNet-18-shaped encoder under "
                     "autocast, 8 camera hypotheses x (4 + 4 mirrored) images = 64 rendered images per pass, RGB + "
                     "silhouette + 8 part maps from 2 shared passes, Chamfer, Laplacian + flatten, distance-map "
-                    "loss, clip + Adam x2; LPIPS replaced by L1 (weights absent)",
+                    "loss, clip + fused Adam x2; LPIPS replaced by L1 (weights absent)",
             "batch_per_rank": o.batch_size, "rendered_images_per_pass": 16 * o.batch_size, "steps": steps,
             "ms_per_step": 1e3 * dt / steps, "dataset_images_per_s_per_rank": per_rank,
             "dataset_images_per_s": per_rank * world, "ranks": world, "hip_graph": graphed,

@@ -25,9 +25,16 @@ per batch.
 launches and is bound by the host issuing them, not by the GPU.  After `GRAPH_EAGER_STEPS`
 ordinary steps the trainer captures forward + loss + backward once in a HIP graph
 (`torch.cuda.CUDAGraph`) over static copies of the inputs a subclass names in `graph_inputs`, and
-from then on replays it; unscale, clipping, the optimizer steps and the scaler update stay eager
-(GradScaler's step reads its inf check on the host).  Everything in the captured part must be
-free of host synchronisation and of shapes that change from step to step.
+from then on replays it; unscale, clipping, the optimizer steps and the scaler update stay eager.
+`--cuda_graph 2` captures those too, so that a step is one replay plus the copy of its inputs: it
+needs `--fused_adam 1`, whose step takes the scaler's inf check as a device tensor (the unfused
+optimizers make GradScaler read that check on the host, which a capture cannot hold).  Everything
+in the captured part must be free of host synchronisation and of shapes that change from step to
+step.
+
+`--fused_adam 1` (default on a GPU): the reference's `torch.optim.Adam(lr, betas=(beta1, 0.999))`
+(:165-172) with `fused=True` -- the same update rule in one multi-tensor kernel per optimizer
+instead of a dozen, and no host read of the inf check in `GradScaler.step`.
 """
 import argparse
 import gc
@@ -67,7 +74,11 @@ def add_training_flags(parser=None):
     p.add_argument('--seed', type=int, default=0)
     p.add_argument('--cuda_graph', type=int, default=0,
                    help='1: after a few eager steps, capture forward + loss + backward of a step in a HIP graph '
-                        'and replay it (single process, constant batch shape; the optimizer steps stay eager)')
+                        'and replay it (single process, constant batch shape; the optimizer steps stay eager); '
+                        '2: capture unscale, clipping, the Adam steps and the scaler update as well '
+                        '(needs --fused_adam 1)')
+    p.add_argument('--fused_adam', type=int, default=1,
+                   help="on a GPU, Adam with fused=True: the reference's update rule in one kernel per optimizer")
     return p
 
 
@@ -215,7 +226,9 @@ class Trainer(object):
         def make(params):
             if opts.use_sgd:
                 return torch.optim.SGD(params, lr=opts.learning_rate, momentum=opts.beta1)
-            return torch.optim.Adam(params, lr=opts.learning_rate, betas=(opts.beta1, 0.999))
+            fused = self.device.type == 'cuda' and bool(getattr(opts, 'fused_adam', 1))
+            return torch.optim.Adam(params, lr=opts.learning_rate, betas=(opts.beta1, 0.999),
+                                    **({'fused': True} if fused else {}))
 
         self.optimizer = make(self.model.parameters())
         if self._second_optimizer():
@@ -263,13 +276,46 @@ class Trainer(object):
             self.forward(total_steps)
         scaler.scale(self.total_loss).backward()
 
+    def _optimizer_steps(self, scaler):
+        """unscale -> clip_grad_norm_ -> step for each optimizer, then the scaler update
+        (train_utils.py:201-214)."""
+        clip = getattr(self.opts, 'grad_clip', 0.1)
+        scaler.unscale_(self.optimizer)
+        torch.nn.utils.clip_grad_norm_(self.model.parameters(), clip)
+        scaler.step(self.optimizer)
+        if self._second_optimizer():
+            scaler.unscale_(self.optimizer_2)
+            torch.nn.utils.clip_grad_norm_(self.part_basis_generator.parameters(), clip)
+            scaler.step(self.optimizer_2)
+        scaler.update()
+
     def _graph_wanted(self):
-        return bool(getattr(self.opts, 'cuda_graph', 0)) and self.device.type == 'cuda' \
+        return int(getattr(self.opts, 'cuda_graph', 0)) > 0 and self.device.type == 'cuda' \
             and not self.env.distributed and len(self.graph_inputs) > 0
 
+    def _graph_whole_step(self):
+        return int(getattr(self.opts, 'cuda_graph', 0)) >= 2
+
+    def _make_optimizers_capturable(self):
+        """A captured optimizer step must keep its step counts on the device and take the inf check
+        as a tensor: Adam with fused=True does both once its groups are marked capturable."""
+        opts = [self.optimizer] + ([self.optimizer_2] if self._second_optimizer() else [])
+        for opt in opts:
+            if not isinstance(opt, torch.optim.Adam) or not all(g.get('fused') for g in opt.param_groups):
+                raise RuntimeError('--cuda_graph 2 captures the optimizer steps and needs Adam with --fused_adam 1 '
+                                   '(not --use_sgd); use --cuda_graph 1 to keep the optimizer steps eager')
+            for g in opt.param_groups:
+                g['capturable'] = True
+
     def _forward_backward_graphed(self, total_steps, scaler):
-        """Forward + loss + backward of this step from the captured graph (captured here on first use)."""
+        """Forward + loss + backward of this step (and, with `--cuda_graph 2`, the optimizer steps)
+        from the captured graph (captured here on first use)."""
+        whole = self._graph_whole_step()
+        if self._graph is not None and self._graph['whole'] != whole:
+            self._graph = None          # the mode changed between two train() calls: capture again
         if self._graph is None:
+            if whole:
+                self._make_optimizers_capturable()
             static = {name: torch.empty_like(getattr(self, name)) for name in self.graph_inputs}
             for name, buf in static.items():
                 buf.copy_(getattr(self, name))
@@ -294,7 +340,9 @@ class Trainer(object):
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
                 self._forward_backward(total_steps, scaler)
-            self._graph = {'graph': graph, 'static': static, 'loss': self.total_loss}
+                if whole:
+                    self._optimizer_steps(scaler)
+            self._graph = {'graph': graph, 'static': static, 'loss': self.total_loss, 'whole': whole}
         else:
             for name, buf in self._graph['static'].items():
                 src = getattr(self, name)
@@ -311,7 +359,8 @@ class Trainer(object):
         self.set_input(batch)
         if self.skip_step():
             return False
-        if self._graph_wanted() and self._graph_eager_steps >= self.GRAPH_EAGER_STEPS:
+        graphed = self._graph_wanted() and self._graph_eager_steps >= self.GRAPH_EAGER_STEPS
+        if graphed:
             self._forward_backward_graphed(total_steps, scaler)
         else:
             self._graph_eager_steps += 1
@@ -319,15 +368,8 @@ class Trainer(object):
             self._forward_backward(total_steps, scaler)
         # the reference's smoothed loss (:194), kept on the device: no host sync per step
         self.smoothed_total_loss = self.smoothed_total_loss * 0.99 + 0.01 * self.total_loss.detach().float()
-        clip = getattr(opts, 'grad_clip', 0.1)
-        scaler.unscale_(self.optimizer)
-        torch.nn.utils.clip_grad_norm_(self.model.parameters(), clip)
-        scaler.step(self.optimizer)
-        if self._second_optimizer():
-            scaler.unscale_(self.optimizer_2)
-            torch.nn.utils.clip_grad_norm_(self.part_basis_generator.parameters(), clip)
-            scaler.step(self.optimizer_2)
-        scaler.update()
+        if not (graphed and self._graph['whole']):
+            self._optimizer_steps(scaler)
         return True
 
     def train(self):

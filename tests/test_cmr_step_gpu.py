@@ -102,6 +102,91 @@ def test_captured_step_matches_the_eager_step(tmp_path):
         t._forward_backward_graphed(0, scaler)
 
 
+def test_whole_captured_step_matches_the_eager_step(tmp_path):
+    """--cuda_graph 2: unscale, clipping, the two fused Adam steps and the scaler update are part of
+    the captured step.  From one state (weights, BatchNorm statistics, Adam moments and step counts,
+    loss scale) and one batch, a replayed step and an eager step must move the weights the same way;
+    the step counts on the device advance once per replay; an unfused optimizer is refused."""
+    import copy
+    import cmr_synthetic
+    argv = ["--num_iter", "7", "--batch_size", "2", "--img_size", "64", "--subdivide", "2", "--tex_size", "4",
+            "--num_parts", "3", "--seg_train", "1", "--checkpoint_dir", str(tmp_path), "--print_scalars", "0",
+            "--dataset_size", "32", "--learning_rate", "1e-3", "--cuda_graph", "2"]
+    o = cmr_synthetic.parse(argv)
+    o.epoch_fraction = 1.0
+    t = cmr_synthetic.ShapeTrainer(o)
+    t.init_training()
+    # a loss scale no fp16 gradient of this step overflows at, so that no step is skipped and the
+    # step counts below are exact (a skipped step takes its count back)
+    t._scaler = torch.amp.GradScaler("cuda", init_scale=256.0)
+    assert t.train() == 7                                   # 3 eager steps, capture + replay, 3 more replays
+    assert t._graph is not None and t._graph["whole"] and torch.isfinite(t.total_loss)
+    params = [p for m in (t.model, t.part_basis_generator) for p in m.parameters() if p.requires_grad]
+    steps = [st["step"] for opt in (t.optimizer, t.optimizer_2) for st in opt.state.values()]
+    assert steps and all(s.is_cuda and float(s) == 7.0 for s in steps)
+    scaler = t._scaler
+    # every tensor a step changes, saved and restored in place (the graph holds their addresses)
+    live = list(params) + list(t.model.buffers()) + [scaler._scale, scaler._growth_tracker]
+    for opt in (t.optimizer, t.optimizer_2):
+        for st in opt.state.values():
+            live += [v for v in st.values() if torch.is_tensor(v)]
+    start = [v.detach().clone() for v in live]
+
+    def restore():
+        with torch.no_grad():
+            for v, s0 in zip(live, start):
+                v.copy_(s0)
+
+    batch = next(iter(t.dataloader))
+    w0 = [p.detach().clone() for p in params]
+    assert t.train_step(batch, 0, scaler)                   # replayed whole step
+    torch.cuda.synchronize()
+    moved_g = [p.detach() - a for p, a in zip(params, w0)]
+    assert all(float(s) == 8.0 for s in steps)
+    restore()
+    o.cuda_graph = 0                                        # the same step, eager
+    graph_grads = [p.grad for p in params]
+    assert t.train_step(batch, 0, scaler)
+    torch.cuda.synchronize()
+    moved_e = [p.detach() - a for p, a in zip(params, w0)]
+    # Adam divides every gradient entry by its running magnitude, so entries whose gradient is
+    # rounding noise move by a full learning rate in a direction the last bits decide; the step is
+    # not bit-repeatable (the convolution library may pick another algorithm under capture).  The
+    # same eager step from the same state with the shape head perturbed by one part in 1e6 gives
+    # the size of that effect.
+    restore()
+    with torch.no_grad():
+        for p in t.model.shape.parameters():
+            p.mul_(1.0 + 1e-6)
+    w1 = [p.detach().clone() for p in params]
+    assert t.train_step(batch, 0, scaler)
+    torch.cuda.synchronize()
+    moved_p = [p.detach() - a for p, a in zip(params, w1)]
+    for p, g in zip(params, graph_grads):                   # hand the captured gradient buffers back
+        p.grad = g
+    o.cuda_graph = 2
+
+    def cosine(xs, ys):
+        dot = sum(float((a.double() * b.double()).sum()) for a, b in zip(xs, ys))
+        nx = sum(float(a.double().pow(2).sum()) for a in xs) ** 0.5
+        ny = sum(float(b.double().pow(2).sum()) for b in ys) ** 0.5
+        assert nx > 0 and ny > 0
+        return dot / (nx * ny), nx, ny
+
+    got, ng, ne = cosine(moved_g, moved_e)
+    floor, _, _ = cosine(moved_p, moved_e)
+    print("whole captured step vs eager step: cosine of the weight updates %.6f (one-in-1e6 perturbation %.6f), "
+          "lengths %.4e / %.4e" % (got, floor, ng, ne))
+    assert 1.0 - got < max(4.0 * (1.0 - floor), 0.02) and got > 0.9 and abs(ng / ne - 1.0) < 0.05
+    # the optimizer must be the fused Adam
+    o2 = cmr_synthetic.parse(argv + ["--fused_adam", "0", "--name", "unfused"])
+    o2.epoch_fraction = 1.0
+    t2 = cmr_synthetic.ShapeTrainer(o2)
+    t2.init_training()
+    with pytest.raises(RuntimeError, match="fused_adam"):
+        t2.train()
+
+
 def test_two_ranks_on_one_gpu_stay_in_lockstep(tmp_path):
     """The whole step under DistributedDataParallel with device-bound wrappers, two ranks sharing
     this GPU (gradients through gloo: RCCL wants a GPU per rank): both DDP-wrapped modules -- the
