@@ -141,8 +141,14 @@ class ShapeTrainer(train_utils.Trainer):
         o = self.opts
         ds = SyntheticCUB(o.dataset_size, o.img_size, seed=1)
         sampler = self.make_sampler(ds)
+        # worker processes and pinned batches as in the reference's loader (data/base.py:215-222,
+        # n_data_workers = 4): preparing a batch on the training process's own thread costs more host
+        # time than issuing the whole step.  The workers outlive an epoch (train() may be called again).
+        workers = max(int(o.n_data_workers), 0)
         self.dataloader = torch.utils.data.DataLoader(ds, batch_size=o.batch_size, sampler=sampler,
-                                                      shuffle=sampler is None, drop_last=True, num_workers=0)
+                                                      shuffle=sampler is None, drop_last=True, num_workers=workers,
+                                                      pin_memory=self.device.type == 'cuda',
+                                                      persistent_workers=workers > 0)
 
     def define_model(self):
         o = self.opts
@@ -239,6 +245,7 @@ def parse(argv=None):
     p.add_argument('--num_parts', type=int, default=8)
     p.add_argument('--chamf_loss_wt', type=float, default=1.0)
     p.add_argument('--dataset_size', type=int, default=512)
+    p.add_argument('--n_data_workers', type=int, default=4, help='loader worker processes (data/base.py:43)')
     p.add_argument('--channels_last', type=int, default=0, help='encoder weights and activations in NHWC')
     p.add_argument('--warmup_iter', type=int, default=0, help='untimed steps before the timed ones')
     p.add_argument('--dt_loss_wt', type=float, default=0.01, help='weight of the texture-flow distance-map loss')
