@@ -120,6 +120,13 @@ int sv3d_raster_backward_timed(const sv3d_raster_params *p, const float *texture
                                float *grad_textures, void *workspace, size_t workspace_bytes,
                                void *stream, void *ev_start, void *ev_stop);
 
+/* Tuning and test hook, no counterpart in the reference.  The backward's waves walk either every
+ * pixel of a face's box or, per pixel row, only the interval of columns that can hold an active
+ * pixel; the library picks per launch from raster size and face count.  mode 0 / 1 forces whole
+ * boxes / row intervals for every later launch of the process, -1 gives the choice back.  Both
+ * forms compute the same sums in a different order (results agree to rounding). */
+int sv3d_raster_backward_spans(int mode);
+
 /* Replaces chamferdist's forward as called at nnutils/loss_utils.py:85-86
  * (`ChamferDistance()(xyz1, xyz2)`).
  *   xyz1 [B,N,3], xyz2 [B,M,3] -> dist1 [B,N], dist2 [B,M] (SQUARED distances),

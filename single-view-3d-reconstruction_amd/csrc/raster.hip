@@ -25,6 +25,8 @@
 #include <math.h>
 #include <stdint.h>
 
+#include <atomic>
+
 #include "camera.h"
 #include "sv3d_hip.h"
 
@@ -1034,7 +1036,11 @@ __device__ inline float wave_sum_lane63(float v)
 // HALVES = 2 (small launches): two waves per face, each taking every other 64-pixel step and
 // the first of them adding the second's totals, exchanged through LDS, before it writes.  With
 // few faces the launch is bound by its longest waves, not by issue slots, and this halves them.
-template <int MODE, bool LO, int HALVES>
+// SPANS: which pixels of the face's box the lanes walk.  false: all of them, row-major.  true: per
+// pixel row only the interval of columns that can hold an active pixel (below).  Finding a lane's
+// row then costs a short search per step, which pays once the faces are large enough in pixels
+// (the host decides from raster size and face count).
+template <int MODE, bool LO, int HALVES, bool SPANS>
 __global__ __launch_bounds__(kThreads) void raster_backward_kernel(
     DevParams P, const float4 *__restrict__ rec, const uint2 *__restrict__ pbox,
     const float *__restrict__ tex, const float *__restrict__ saved, const float *__restrict__ grad_rgba,
@@ -1093,7 +1099,6 @@ __global__ __launch_bounds__(kThreads) void raster_backward_kernel(
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     // the record and the box are here
     const unsigned long long trace_ta = __builtin_amdgcn_s_memrealtime() + (unsigned long long)(r.p0x != 12345.f ? 0 : 1);
 #endif
-    const float inv_bw = bw > 0 ? rcp((float)bw) : 0.f;     // the two fix-ups below absorb its last-bit error
 
     // SURFACE: the face's texel gradients accumulate in wave-private LDS tables.  Lanes of one
     // step mostly hit the same few texels, so small textures get four tables (lane & 3 picks one,
@@ -1125,25 +1130,39 @@ __global__ __launch_bounds__(kThreads) void raster_backward_kernel(
 #pragma unroll
     for (int i = 0; i < 3 * NC; ++i) tacc[i] = 0.f;
 
-    // Lanes enumerate the box row-major, 64 pixels per step.  (rx, ry) = position inside the box,
-    // kept as exact small integers in fp32 and advanced by kStride pixels per step with at most one
-    // row wrap per lane; the per-pixel inputs of step i+1 are requested before step i is
-    // evaluated so that their latency overlaps the arithmetic.
+    // SPANS: lanes enumerate, row by row, the pixels of the box that can be active at all, 64 per
+    // step.  A pixel is active only if it is inside the face or nearer to it than the cull distance,
+    // so it lies on the inner side of every edge line moved outwards by that distance: on each pixel
+    // row that is one interval of columns (the box is the bounding box of this set grown by the
+    // same distance, and for typical faces a third of it lies outside).  Rows are handled 64 at a
+    // time, one per lane: the lane works out its row's interval [lo, lo + len), a prefix sum of the
+    // lengths numbers the pixels, and a step takes 64 consecutive numbers.  The intervals err on
+    // the wide side; whether a pixel counts is still decided by pair_geom alone.
+    // Otherwise lanes enumerate the whole box row-major, 64 pixels per step: (rx, ry) = position
+    // inside the box, kept as exact small integers in fp32 and advanced by kStride pixels per step
+    // with at most one row wrap per lane.
+    // Either way the per-pixel inputs of step i+1 are requested before step i is evaluated, so that
+    // their latency overlaps the arithmetic.
     const float bw_f = (float)bw, bh_f = (float)bh;
     float xp0, yp0;
     pixel_centre(col0, row0, S, P.inv_S, xp0, yp0);
-    constexpr int kStride = 64 * HALVES;        // pixels between two steps of one wave
-    // kStride = adv_y * bw + adv_x, by the reciprocal and the same fix-ups as the lanes' start below
-    float adv_y = floorf(((float)kStride + 0.5f) * inv_bw);
-    float adv_x = fmaf(-adv_y, bw_f, (float)kStride);
-    if (adv_x < 0.f) { adv_y -= 1.f; adv_x += bw_f; }
-    if (adv_x >= bw_f) { adv_y += 1.f; adv_x -= bw_f; }
-    if (bw <= 0) adv_x = adv_y = 0.f;
-    const float lane0 = (float)(half * 64 + lane);
-    float ry_f = floorf((lane0 + 0.5f) * inv_bw);
-    float rx_f = fmaf(-ry_f, bw_f, lane0);
-    if (rx_f < 0.f) { ry_f -= 1.f; rx_f += bw_f; }
-    if (rx_f >= bw_f) { ry_f += 1.f; rx_f -= bw_f; }
+    constexpr int kStride = 64 * HALVES;        // pixel numbers between two steps of one wave
+    const int rows_live = npix > 0 ? bh : 0;
+    float adv_x = 0.f, adv_y = 0.f, rx_f = 0.f, ry_f = 0.f;
+    if (!SPANS) {
+        const float inv_bw = bw > 0 ? rcp((float)bw) : 0.f;     // the fix-ups below absorb its last-bit error
+        // kStride = adv_y * bw + adv_x, by the reciprocal and the same fix-ups as the lanes' start below
+        adv_y = floorf(((float)kStride + 0.5f) * inv_bw);
+        adv_x = fmaf(-adv_y, bw_f, (float)kStride);
+        if (adv_x < 0.f) { adv_y -= 1.f; adv_x += bw_f; }
+        if (adv_x >= bw_f) { adv_y += 1.f; adv_x -= bw_f; }
+        if (bw <= 0) adv_x = adv_y = 0.f;
+        const float lane0 = (float)(half * 64 + lane);
+        ry_f = floorf((lane0 + 0.5f) * inv_bw);
+        rx_f = fmaf(-ry_f, bw_f, lane0);
+        if (rx_f < 0.f) { ry_f -= 1.f; rx_f += bw_f; }
+        if (rx_f >= bw_f) { ry_f += 1.f; rx_f -= bw_f; }
+    }
 
     // Raw per-pixel inputs: the forward's saved aggregates and the incoming gradient.  They are
     // combined where they are used, so that the loads stay in flight across a step.
@@ -1160,10 +1179,62 @@ __global__ __launch_bounds__(kThreads) void raster_backward_kernel(
     auto at32 = [](const float *base, unsigned index) -> float {
         return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(base) + index * 4u);
     };
-    auto fetch = [&]() {                            // inputs of the pixel at the current (rx, ry)
+    // SPANS, of the current 64 rows: inclusive prefix sum of the interval lengths, start << 12 | lo
+    // per row, pixels in all, first row.  Otherwise span_total is the box's pixel count.
+    int span_cum = 0, span_pack = 0, span_total = SPANS ? 0 : npix, span_row0 = 0;
+    auto fetch = [&](int base) {                    // inputs of pixel number base + lane
         PixIn in;
-        in.valid = ry_f < bh_f;
-        const float cx = in.valid ? rx_f : 0.f, cy = in.valid ? ry_f : 0.f;
+        float cx, cy;
+        if (SPANS) {
+            const int pnum = base + lane;
+            in.valid = pnum < span_total;
+            // The rows this step touches run from the one holding number `base` to the one holding
+            // the step's last number; a lane's row is the last of them that starts at or before its
+            // number.  span_pack is ordered like the starts, so it is compared whole.
+            const int last = min(base + 63, span_total - 1);
+            const int r_first = __builtin_ctzll(__ballot(span_cum > base) | (1ull << 63));
+            const int r_last = __builtin_ctzll(__ballot(span_cum > last) | (1ull << 63));
+            const int key = (pnum << 12) | 0xfff;
+            int cur = __builtin_amdgcn_readlane(span_pack, r_first);
+            int rowv = r_first;
+            if (MODE == SV3D_TEX_SURFACE) {
+                // this mode keeps the LDS pipe busy with its texel tables: the rows are walked with
+                // scalar reads of their lanes instead
+                for (int rr = r_first + 1; rr <= r_last; ++rr) {        // wave-uniform
+                    const int pk = __builtin_amdgcn_readlane(span_pack, rr);
+                    const bool ok = pk <= key;
+                    rowv = ok ? rr : rowv;
+                    cur = ok ? pk : cur;
+                }
+            } else {
+                // a descent by halving strides over the row lanes, read through the cross-lane network
+                int pos4 = r_first * 4;                                  // byte index of the row's lane
+                const int more = r_last - r_first;                       // wave-uniform
+                if (more > 0) {
+                    for (int stride4 = 4 << (31 - __builtin_clz(more)); stride4 >= 4; stride4 >>= 1) {
+                        const int cand4 = min(pos4 + stride4, 252);
+                        const int pk = __builtin_amdgcn_ds_bpermute(cand4, span_pack);
+                        const bool ok = pk <= key;
+                        pos4 = ok ? cand4 : pos4;
+                        cur = ok ? pk : cur;
+                    }
+                }
+                rowv = pos4 >> 2;
+            }
+            const int colv = pnum - (cur >> 12) + (cur & 0xfff);
+            cx = in.valid ? (float)colv : 0.f;
+            cy = in.valid ? (float)(span_row0 + rowv) : 0.f;
+        } else {
+            in.valid = ry_f < bh_f;
+            cx = in.valid ? rx_f : 0.f;
+            cy = in.valid ? ry_f : 0.f;
+            // advance to the pixel kStride positions further
+            rx_f += adv_x;
+            ry_f += adv_y;
+            const bool wrap = rx_f >= bw_f;
+            rx_f -= wrap ? bw_f : 0.f;
+            ry_f += wrap ? 1.f : 0.f;
+        }
         in.xp = fmaf(cx, step, xp0);
         in.yp = fmaf(-cy, step, yp0);
         if (LO) {           // remainder of the exact centre over the rounded one, see struct Pixel
@@ -1198,24 +1269,61 @@ __global__ __launch_bounds__(kThreads) void raster_backward_kernel(
 #pragma unroll
             for (int c = 0; c < NC; ++c) in.gch[c] = at32(grad_b + c * plane, gpix);
         }
-        // advance to the pixel 64 positions further
-        rx_f += adv_x;
-        ry_f += adv_y;
-        const bool wrap = rx_f >= bw_f;
-        rx_f -= wrap ? bw_f : 0.f;
-        ry_f += wrap ? 1.f : 0.f;
         return in;
     };
 
-    PixIn nxt;
-    if (npix > half * 64) nxt = fetch();
 #ifdef SV3D_TRACE
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     // the first pixels are here
-    const unsigned long long trace_tb = __builtin_amdgcn_s_memrealtime();
+    unsigned long long trace_tb = trace_ta;
 #endif
-    for (int base = half * 64; base < npix; base += kStride) {
+    // SPANS: 64 rows of the box at a time (mostly all of them); otherwise one pass over the box
+    for (int rg = 0; rg < (SPANS ? rows_live : 1); rg += 64) {
+    if (SPANS) {
+        // Edge k's scaled edge function at column i of a row is W_k - i * g_k (W_k its value at the
+        // box's first column); the moved line is W_k - i * g_k >= -c_k, c_k = margin |e_k| / |det|.
+        // An edge closer to the row direction than 1:16 bounds nothing here (its crossing is too
+        // sensitive to rounding); the slack covers the rounding of the others up to the largest S.
+        const float grow = P.margin * fabsf(r.inv_det) * (1.f + 1.f / 1024.f);
+        const float c_e0 = grow * __builtin_amdgcn_rsqf(r.il0), c_e1 = grow * __builtin_amdgcn_rsqf(r.il1),
+                    c_e2 = grow * __builtin_amdgcn_rsqf(r.il2);
+        const float g_e0 = r.f0y * step, g_e1 = r.f1y * step, g_e2 = r.f2y * step;
+        const bool use_e0 = fabsf(r.e0y) * 16.f > fabsf(r.e0x) && g_e0 != 0.f,
+                   use_e1 = fabsf(r.e1y) * 16.f > fabsf(r.e1x) && g_e1 != 0.f,
+                   use_e2 = fabsf(r.e2y) * 16.f > fabsf(r.e2x) && g_e2 != 0.f;
+        const float ig_e0 = rcp(g_e0), ig_e1 = rcp(g_e1), ig_e2 = rcp(g_e2);
+        const float span_slack = 0.02f + 1.6e-5f * fS;
+        const float ax_e0 = r.p0x - xp0, ax_e1 = r.p1x - xp0, ax_e2 = r.p2x - xp0;
+        const int row_in_box = rg + lane;
+        const float yrow = fmaf(-(float)row_in_box, step, yp0);
+        const float ay0 = r.p0y - yrow, ay1 = r.p1y - yrow, ay2 = r.p2y - yrow;
+        // edge k's function at the first column, plus its allowance, over its change per column
+        const float q0 = (fmaf(r.f0y, ax_e0, -(r.f0x * ay0)) + c_e0) * ig_e0;
+        const float q1 = (fmaf(r.f1y, ax_e1, -(r.f1x * ay1)) + c_e1) * ig_e1;
+        const float q2 = (fmaf(r.f2y, ax_e2, -(r.f2x * ay2)) + c_e2) * ig_e2;
+        float lo_f = 0.f, hi_f = bw_f - 1.f;
+        // g > 0: columns up to q; g < 0: columns from q on (a NaN or an unused edge bounds nothing)
+        if (use_e0) { if (g_e0 > 0.f) hi_f = fminf(hi_f, floorf(q0 + span_slack)); else lo_f = fmaxf(lo_f, ceilf(q0 - span_slack)); }
+        if (use_e1) { if (g_e1 > 0.f) hi_f = fminf(hi_f, floorf(q1 + span_slack)); else lo_f = fmaxf(lo_f, ceilf(q1 - span_slack)); }
+        if (use_e2) { if (g_e2 > 0.f) hi_f = fminf(hi_f, floorf(q2 + span_slack)); else lo_f = fmaxf(lo_f, ceilf(q2 - span_slack)); }
+        lo_f = fminf(lo_f, bw_f);
+        hi_f = fmaxf(hi_f, -1.f);
+        const int lo_i = (int)lo_f;
+        const int len = row_in_box < rows_live ? max((int)hi_f - lo_i + 1, 0) : 0;
+        span_cum = wave_inclusive_scan(len);
+        span_total = __builtin_amdgcn_readlane(span_cum, 63);
+        span_pack = ((span_cum - len) << 12) | lo_i;            // 64 rows of at most 4096 pixels: 18 + 12 bits
+        span_row0 = rg;
+    }
+    PixIn nxt;
+    if (span_total > half * 64) nxt = fetch(half * 64);
+#ifdef SV3D_TRACE
+    if (rg == 0) {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     // the first pixels are here
+        trace_tb = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
+    for (int base = half * 64; base < span_total; base += kStride) {
         const PixIn in = nxt;
-        if (base + kStride < npix) nxt = fetch();   // wave-uniform
+        if (base + kStride < span_total) nxt = fetch(base + kStride);   // wave-uniform
         const float xp = in.xp, yp = in.yp;
         const bool valid = in.valid;
         // fold the gradient with the aggregates: g_alpha A and g_k / ssum
@@ -1326,6 +1434,7 @@ __global__ __launch_bounds__(kThreads) void raster_backward_kernel(
         acc[3] = fmaf(f1, g.dx, acc[3]); acc[4] = fmaf(f1, g.dy, acc[4]);
         acc[6] = fmaf(f2, g.dx, acc[6]); acc[7] = fmaf(f2, g.dy, acc[7]);
     }
+    }
 
 #ifdef SV3D_TRACE
     if (lane == 0 && blockIdx.x * 4 + wave < 16384) {       // stamp at the end of the pixel loop
@@ -1401,6 +1510,9 @@ __global__ __launch_bounds__(kThreads) void raster_backward_kernel(
 // host side
 // ------------------------------------------------------------------------------------
 constexpr long kBackwardHalvesMaxFaces = 16384;
+// -1: the library chooses the backward's pixel enumeration per launch; 0 / 1: whole boxes / row
+// intervals for every launch (tests and tuning, sv3d_raster_backward_spans)
+std::atomic<int> g_backward_spans{-1};
 
 int make_dev_params(const sv3d_raster_params *p, DevParams &d)
 {
@@ -1589,31 +1701,45 @@ int raster_backward_impl(const sv3d_raster_params *p, const float *textures, con
     const bool lo = (d.S & (d.S - 1)) != 0;         // raster size not a power of two: see struct Pixel
     const size_t lds = d.mode == SV3D_TEX_SURFACE ? (size_t)4 * tex_lds_floats(d.R * d.R) * sizeof(float) : 0;
     float *gt = d.mode == SV3D_TEX_NONE ? nullptr : grad_textures;
+    // Interval enumeration once a face covers enough pixels for it to pay: the expected box is a
+    // few times S^2 / F pixels (measured: 1280 faces gain 6..28 % at 512^2 and lose 3..8 % at 256^2;
+    // 5120 faces at 512^2 lose)
+    const int forced = g_backward_spans.load(std::memory_order_relaxed);
+    const bool spans = forced < 0 ? (long)d.S * d.S >= 128L * d.F : forced != 0;
+#define SV3D_BWD_CASE(M, LO_, H_, SP_)                                                                  \
+    hipLaunchKernelGGL((raster_backward_kernel<M, LO_, H_, SP_>), fgrid, block, lds, s, d, rec, pbox,   \
+                       textures, saved, grad_rgba, grad_face_vertices, gt)
+#define SV3D_BWD_SPANS(M, SP_)                                                                          \
+    do {                                                                                                \
+        if (lo && halves) SV3D_BWD_CASE(M, true, 2, SP_);                                               \
+        else if (lo) SV3D_BWD_CASE(M, true, 1, SP_);                                                    \
+        else if (halves) SV3D_BWD_CASE(M, false, 2, SP_);                                               \
+        else SV3D_BWD_CASE(M, false, 1, SP_);                                                           \
+    } while (0)
 #define SV3D_LAUNCH_BWD(M)                                                                              \
     do {                                                                                                \
-        if (lo && halves)                                                                               \
-            hipLaunchKernelGGL((raster_backward_kernel<M, true, 2>), fgrid, block, lds, s, d, rec, pbox,   \
-                               textures, saved, grad_rgba, grad_face_vertices, gt);                     \
-        else if (lo)                                                                                    \
-            hipLaunchKernelGGL((raster_backward_kernel<M, true, 1>), fgrid, block, lds, s, d, rec, pbox,   \
-                               textures, saved, grad_rgba, grad_face_vertices, gt);                     \
-        else if (halves)                                                                                \
-            hipLaunchKernelGGL((raster_backward_kernel<M, false, 2>), fgrid, block, lds, s, d, rec, pbox,  \
-                               textures, saved, grad_rgba, grad_face_vertices, gt);                     \
-        else                                                                                            \
-            hipLaunchKernelGGL((raster_backward_kernel<M, false, 1>), fgrid, block, lds, s, d, rec, pbox,  \
-                               textures, saved, grad_rgba, grad_face_vertices, gt);                     \
+        if (spans) SV3D_BWD_SPANS(M, true);                                                             \
+        else SV3D_BWD_SPANS(M, false);                                                                  \
     } while (0)
     if (d.mode == SV3D_TEX_NONE) SV3D_LAUNCH_BWD(SV3D_TEX_NONE);
     else if (d.mode == SV3D_TEX_SURFACE) SV3D_LAUNCH_BWD(SV3D_TEX_SURFACE);
     else if (d.mode == SV3D_TEX_VERTEX) SV3D_LAUNCH_BWD(SV3D_TEX_VERTEX);
     else SV3D_LAUNCH_BWD(SV3D_TEX_VERTEX8);
 #undef SV3D_LAUNCH_BWD
+#undef SV3D_BWD_SPANS
+#undef SV3D_BWD_CASE
     if (ev_stop) (void)hipEventRecord(ev_stop, s);
     return launch_status();
 }
 
 }  // namespace
+
+extern "C" int sv3d_raster_backward_spans(int mode)
+{
+    if (mode < -1 || mode > 1) return SV3D_ERR_INVALID_ARG;
+    g_backward_spans.store(mode, std::memory_order_relaxed);
+    return SV3D_OK;
+}
 
 extern "C" int sv3d_raster_forward(const sv3d_raster_params *p, const float *face_vertices,
                                    const float *textures, float *rgba_out, void *face_rec,

@@ -14,7 +14,7 @@ SV3D_TEX_NONE, SV3D_TEX_SURFACE, SV3D_TEX_VERTEX, SV3D_TEX_VERTEX8 = 0, 1, 2, 3
 
 EXPORTS = (
     "sv3d_strerror", "sv3d_abi_version", "sv3d_raster_sizes", "sv3d_raster_forward",
-    "sv3d_raster_backward", "sv3d_raster_forward_timed", "sv3d_raster_backward_timed",
+    "sv3d_raster_backward", "sv3d_raster_forward_timed", "sv3d_raster_backward_timed", "sv3d_raster_backward_spans",
     "sv3d_chamfer_forward", "sv3d_chamfer_backward",
     "sv3d_face_gather", "sv3d_face_scatter",
     "sv3d_project_gather", "sv3d_project_scatter", "sv3d_render_forward",
@@ -76,6 +76,7 @@ def lib():
         L.sv3d_raster_backward.argtypes = [pp, vp, vp, vp, vp, vp, vp, vp, sz, vp]
         L.sv3d_raster_forward_timed.argtypes = [pp, vp, vp, vp, vp, vp, vp, vp, vp]
         L.sv3d_raster_backward_timed.argtypes = [pp, vp, vp, vp, vp, vp, vp, vp, sz, vp, vp, vp]
+        L.sv3d_raster_backward_spans.argtypes = [ctypes.c_int]
         L.sv3d_chamfer_forward.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp, vp, vp]
         L.sv3d_chamfer_backward.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp]
         f3 = ctypes.POINTER(ctypes.c_float)

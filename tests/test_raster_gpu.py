@@ -29,6 +29,17 @@ COLOUR_GAMMA_1E4_TOL = 1e-5
 _LOG = []
 
 
+@pytest.fixture(autouse=True, params=["boxes", "spans"])
+def backward_enumeration(request):
+    """Every test of this file runs with both forms of the backward's pixel enumeration (whole
+    boxes, row intervals); left to itself the library picks one per launch."""
+    from sv3d import _lib as L
+    lib = L.lib()
+    assert lib.sv3d_raster_backward_spans(1 if request.param == "spans" else 0) == 0
+    yield request.param
+    assert lib.sv3d_raster_backward_spans(-1) == 0
+
+
 def _record(name, **kw):
     _LOG.append(dict(test=name, **{k: float(v) for k, v in kw.items()}))
     out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
@@ -83,8 +94,8 @@ def _fp32_floor(fv, tex, img, aa, mode, grad, unstable, want, wfv, wtex, **kw):
     single precision costs on this input before any kernel is involved (edge-on faces have
     ill-conditioned barycentrics, which a sharp z-softmax amplifies)."""
     S = img * (2 if aa else 1)
-    x = fv.float().requires_grad_(True)
-    t = tex.float().requires_grad_(True) if tex is not None else None
+    x = fv.detach().clone().float().requires_grad_(True)        # never the caller's own tensors
+    t = tex.detach().clone().float().requires_grad_(True) if tex is not None else None
     rgba, _ = raster_oracle.soft_rasterize(x, t, S, texture_mode=mode, **kw)
     if aa:
         rgba = torch.nn.functional.avg_pool2d(rgba, 2, 2)
@@ -94,7 +105,7 @@ def _fp32_floor(fv, tex, img, aa, mode, grad, unstable, want, wfv, wtex, **kw):
             rel_err(x.grad, wfv), rel_err(t.grad, wtex) if wtex is not None else 0.0)
 
 
-def _compare(name, fv, tex, img, aa, mode, fp32_floor=False, grad_tol=None, img_tol=None, **kw):
+def _compare(name, fv, tex, img, aa, mode, fp32_floor=False, grad_tol=None, img_tol=None, floor_bounds=False, **kw):
     B = fv.shape[0]
     grad = 2 * torch.rand(B, 9 if mode == "vertex8" else 4, img, img, generator=torch.Generator().manual_seed(4)) - 1
     want, wfv, wtex, unstable, nact = _oracle(fv, tex, img, aa, mode, grad, **kw)
@@ -114,6 +125,10 @@ def _compare(name, fv, tex, img, aa, mode, fp32_floor=False, grad_tol=None, img_
         # from their fp64 evaluation on this input (recorded beside the kernel's own error)
         itol, ftol, ttol = _fp32_floor(fv, tex, img, aa, mode, grad, unstable, want, wfv, wtex, **kw)
         _record(name + "_fp32_oracle_floor", img=itol, grad_fv=ftol, grad_tex=ttol, unstable=frac, active=sum(nact))
+        if floor_bounds:
+            # ill-conditioned inputs on purpose: the bar is the stated one or what the formulas
+            # themselves lose in single precision on this input, whichever is larger
+            gtol = max(gtol, ftol, ttol)
     assert e_img < (img_tol if img_tol is not None else IMG_TOL), ("image", e_img)
     assert e_fv < gtol, ("grad_face_vertices", e_fv)
     assert e_tex < gtol, ("grad_textures", e_tex)
@@ -481,3 +496,24 @@ def test_many_faces_take_the_coarse_bin_path(mode):
             prod = prod * (1 - part[:, 3])
         whole = sv3d.soft_rasterize(x, None, 192, sigma_val=3e-5)
         assert rel_err((1 - whole[:, 3]).cpu(), prod.cpu()) < 1e-6
+
+
+@pytest.mark.parametrize("mode", ["none", "surface", "vertex8"])
+def test_faces_taller_than_a_row_group_and_awkward_shapes(mode):
+    """Faces whose pixel box has more than 64 rows (the interval enumeration handles 64 rows at a
+    time), a sliver, an edge within a hair of the row direction, a face that leaves the screen on
+    two sides and one that misses it: image and gradients against the oracle."""
+    fv = torch.tensor([[
+        [[-0.85, -0.80, 3.0], [0.80, -0.60, 3.2], [-0.10, 0.85, 2.9]],       # ~210 rows at 256
+        [[-0.90, 0.70, 2.5], [0.90, 0.7005, 2.6], [0.20, 0.10, 2.4]],        # one edge almost horizontal
+        [[-0.60, -0.90, 2.2], [-0.58, 0.90, 2.3], [-0.57, -0.90, 2.25]],     # sliver, 230 rows
+        [[0.30, -1.60, 3.5], [1.70, 0.20, 3.4], [0.40, 0.30, 3.6]],          # leaves the screen
+        [[1.30, 1.30, 3.0], [1.60, 1.30, 3.0], [1.40, 1.70, 3.0]],           # off screen
+        [[0.10, -0.30, 2.0], [0.55, -0.30, 2.1], [0.30, 0.20, 2.05]],        # horizontal edge, exactly
+    ]], dtype=torch.float32)
+    tex = _textures(mode, 1, fv.shape[1], 3)      # few texel boundaries: the faces are large
+    for img, aa, sigma in ((256, False, 1e-4), (160, True, 3e-5), (100, False, 1e-3)):
+        # the sliver's barycentrics are ill-conditioned (its determinant is a few 1e-2 of its edges'
+        # products): the fp32 floor of the oracle's own formulas is recorded beside the kernels' error
+        _compare("tall_%s_%d" % (mode, img), fv, tex, img, aa, mode, sigma=sigma, gamma=1e-2, fp32_floor=True,
+                 grad_tol=5e-5, floor_bounds=True)
