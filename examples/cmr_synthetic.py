@@ -134,6 +134,61 @@ class SyntheticCUB(torch.utils.data.Dataset):
         return torch.rand(3, self.img_size, self.img_size, generator=g) * self.disk, self.disk
 
 
+class ThreadedLoader(object):
+    """Runs a DataLoader's iterator on a background thread, a few batches ahead of the consumer.
+    The batch preparation (tensor ops that release the interpreter lock) then overlaps with the
+    training thread's kernel launches without any further process."""
+
+    def __init__(self, loader, depth=3):
+        self.loader, self.depth = loader, depth
+        self._stop = None
+
+    def __len__(self):
+        return len(self.loader)
+
+    @property
+    def sampler(self):
+        return self.loader.sampler
+
+    def __iter__(self):
+        import queue
+        import threading
+        if self._stop is not None:
+            self._stop.set()                    # an iterator left mid-epoch: let its thread end
+        stop, q, done = threading.Event(), queue.Queue(maxsize=self.depth), object()
+        self._stop = stop
+
+        def produce():
+            try:
+                for batch in self.loader:
+                    while not stop.is_set():
+                        try:
+                            q.put(batch, timeout=0.1)
+                            break
+                        except queue.Full:
+                            pass
+                    if stop.is_set():
+                        return
+                item = done
+            except BaseException as e:          # hand the failure to the consumer
+                item = e
+            while not stop.is_set():
+                try:
+                    q.put(item, timeout=0.1)
+                    return
+                except queue.Full:
+                    pass
+
+        threading.Thread(target=produce, daemon=True).start()
+        while True:
+            item = q.get()
+            if item is done:
+                return
+            if isinstance(item, BaseException):
+                raise item
+            yield item
+
+
 class ShapeTrainer(train_utils.Trainer):
     graph_inputs = ('imgs', 'masks')
 
@@ -141,14 +196,17 @@ class ShapeTrainer(train_utils.Trainer):
         o = self.opts
         ds = SyntheticCUB(o.dataset_size, o.img_size, seed=1)
         sampler = self.make_sampler(ds)
-        # worker processes and pinned batches as in the reference's loader (data/base.py:215-222,
-        # n_data_workers = 4): preparing a batch on the training process's own thread costs more host
-        # time than issuing the whole step.  The workers outlive an epoch (train() may be called again).
+        # Batches are prepared off the training thread and pinned: with the renders this fast, preparing
+        # one on the training thread costs more host time than issuing the whole step.  The reference
+        # does that with worker processes (data/base.py:215-222, n_data_workers = 4), available here as
+        # --n_data_workers; the default is one background thread, which needs no further process.
         workers = max(int(o.n_data_workers), 0)
         self.dataloader = torch.utils.data.DataLoader(ds, batch_size=o.batch_size, sampler=sampler,
                                                       shuffle=sampler is None, drop_last=True, num_workers=workers,
                                                       pin_memory=self.device.type == 'cuda',
                                                       persistent_workers=workers > 0)
+        if workers == 0 and o.loader_thread:
+            self.dataloader = ThreadedLoader(self.dataloader)
 
     def define_model(self):
         o = self.opts
@@ -245,7 +303,9 @@ def parse(argv=None):
     p.add_argument('--num_parts', type=int, default=8)
     p.add_argument('--chamf_loss_wt', type=float, default=1.0)
     p.add_argument('--dataset_size', type=int, default=512)
-    p.add_argument('--n_data_workers', type=int, default=4, help='loader worker processes (data/base.py:43)')
+    p.add_argument('--n_data_workers', type=int, default=0, help='loader worker processes (data/base.py:43)')
+    p.add_argument('--loader_thread', type=int, default=1,
+                   help='with no worker processes: prepare batches on a background thread, three ahead')
     p.add_argument('--channels_last', type=int, default=0, help='encoder weights and activations in NHWC')
     p.add_argument('--warmup_iter', type=int, default=0, help='untimed steps before the timed ones')
     p.add_argument('--dt_loss_wt', type=float, default=0.01, help='weight of the texture-flow distance-map loss')
