@@ -1702,10 +1702,10 @@ int raster_backward_impl(const sv3d_raster_params *p, const float *textures, con
     const size_t lds = d.mode == SV3D_TEX_SURFACE ? (size_t)4 * tex_lds_floats(d.R * d.R) * sizeof(float) : 0;
     float *gt = d.mode == SV3D_TEX_NONE ? nullptr : grad_textures;
     // Interval enumeration once a face covers enough pixels for it to pay: the expected box is a
-    // few times S^2 / F pixels (measured: 1280 faces gain 6..28 % at 512^2 and lose 3..8 % at 256^2;
-    // 5120 faces at 512^2 lose)
+    // few times S^2 / F pixels (measured with 1280 faces: 320^2 -8 %, 384^2 -6..12 %, 512^2
+    // -13..28 %, but 256^2 +2..3 %; 5120 faces: 1024^2 -15 %, 512^2 +7 %; 320 faces at 256^2 -11 %)
     const int forced = g_backward_spans.load(std::memory_order_relaxed);
-    const bool spans = forced < 0 ? (long)d.S * d.S >= 128L * d.F : forced != 0;
+    const bool spans = forced < 0 ? (long)d.S * d.S >= 64L * d.F : forced != 0;
 #define SV3D_BWD_CASE(M, LO_, H_, SP_)                                                                  \
     hipLaunchKernelGGL((raster_backward_kernel<M, LO_, H_, SP_>), fgrid, block, lds, s, d, rec, pbox,   \
                        textures, saved, grad_rgba, grad_face_vertices, gt)

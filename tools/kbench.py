@@ -35,6 +35,12 @@ CONFIGS = {
     "ref_rgb_b8": (8, 256, True, 3, 1e-5, "surface", 6),
     "ref_rgb_b16": (16, 256, True, 3, 1e-5, "surface", 6),
     # batch sweep at the benchmark configuration: either side of the kernels' launch-size thresholds
+    # face size sweep for the backward's enumeration choice (pixels per face ~ S^2 / F)
+    "s384": (32, 384, False, 3, 1e-4, "none", 1),
+    "s384_rgb": (32, 384, False, 3, 1e-5, "surface", 6),
+    "s256_f320": (64, 256, False, 2, 1e-4, "none", 1),
+    "s1024_f5120": (16, 512, True, 4, 1e-5, "none", 1),
+    "s320_rgb": (32, 320, False, 3, 1e-5, "surface", 6),
     "c2b2": (2, 256, False, 3, 1e-4, "none", 1),
     "c2b4": (4, 256, False, 3, 1e-4, "none", 1),
     "c2b12": (12, 256, False, 3, 1e-4, "none", 1),
@@ -56,6 +62,8 @@ def main():
     ap.add_argument("--iters", type=int, default=30)
     ap.add_argument("--json", default="")
     ap.add_argument("--alpha-only", type=int, default=0, help="silhouette configs: alpha plane alone")
+    ap.add_argument("--bwd-spans", type=int, default=-1,
+                    help="backward pixel enumeration: -1 the library's choice, 0 whole boxes, 1 row intervals")
     args = ap.parse_args()
 
     from sv3d import _lib as L, workmodel
@@ -69,6 +77,8 @@ def main():
         h.sv3d_raster_sizes.argtypes = [pp, ctypes.POINTER(sz), ctypes.POINTER(sz), ctypes.POINTER(sz)]
         h.sv3d_raster_forward_timed.argtypes = [pp, vp, vp, vp, vp, vp, vp, vp, vp]
         h.sv3d_raster_backward_timed.argtypes = [pp, vp, vp, vp, vp, vp, vp, vp, sz, vp, vp, vp]
+        if hasattr(h, "sv3d_raster_backward_spans"):
+            assert h.sv3d_raster_backward_spans(ctypes.c_int(args.bwd_spans)) == 0
         handles.append(h)
     ev = bench.HipEvents()
     dev = torch.device("cuda:0")
