@@ -1304,7 +1304,7 @@ __global__ __launch_bounds__(kThreads) void raster_backward_kernel(
         if (use_e0) { if (g_e0 > 0.f) hi_f = fminf(hi_f, floorf(q0 + span_slack)); else lo_f = fmaxf(lo_f, ceilf(q0 - span_slack)); }
         if (use_e1) { if (g_e1 > 0.f) hi_f = fminf(hi_f, floorf(q1 + span_slack)); else lo_f = fmaxf(lo_f, ceilf(q1 - span_slack)); }
         if (use_e2) { if (g_e2 > 0.f) hi_f = fminf(hi_f, floorf(q2 + span_slack)); else lo_f = fmaxf(lo_f, ceilf(q2 - span_slack)); }
-        lo_f = fminf(lo_f, bw_f);
+        lo_f = fminf(lo_f, bw_f - 1.f);             // 12 bits hold it; an empty row may gain its last pixel
         hi_f = fmaxf(hi_f, -1.f);
         const int lo_i = (int)lo_f;
         const int len = row_in_box < rows_live ? max((int)hi_f - lo_i + 1, 0) : 0;
