@@ -517,3 +517,42 @@ def test_faces_taller_than_a_row_group_and_awkward_shapes(mode):
         # products): the fp32 floor of the oracle's own formulas is recorded beside the kernels' error
         _compare("tall_%s_%d" % (mode, img), fv, tex, img, aa, mode, sigma=sigma, gamma=1e-2, fp32_floor=True,
                  grad_tol=5e-5, floor_bounds=True)
+
+
+@pytest.mark.parametrize("mode", ["none", "surface"])
+def test_backward_enumerations_agree_on_a_large_raster(mode, backward_enumeration):
+    """2048^2 with faces that span most of the screen: boxes of up to ~1900 rows and columns, so the
+    interval enumeration takes dozens of 64-row groups with rows a thousand pixels long.  Too large
+    for the dense oracle; the whole-box enumeration, which the oracle tests pin, is the reference."""
+    if backward_enumeration != "spans":
+        pytest.skip("compares the two enumerations itself")
+    import sv3d
+    from sv3d import _lib as L
+    lib = L.lib()
+    fv = torch.tensor([[
+        [[-0.95, -0.90, 3.0], [0.92, -0.70, 3.2], [-0.20, 0.93, 2.9]],
+        [[-0.90, 0.80, 2.5], [0.95, 0.805, 2.6], [0.30, -0.85, 2.4]],
+        [[-0.70, -0.95, 2.2], [-0.66, 0.95, 2.3], [-0.64, -0.95, 2.25]],
+        [[0.10, -1.80, 3.5], [1.90, 0.10, 3.4], [0.20, 0.40, 3.6]],
+    ]], dtype=torch.float32)
+    img = 2048
+    tex = _textures(mode, 1, fv.shape[1], 4)
+    grad = (2 * torch.rand(1, 4, img, img, generator=torch.Generator().manual_seed(11)) - 1).cuda()
+
+    def run(spans):
+        assert lib.sv3d_raster_backward_spans(spans) == 0
+        x = fv.cuda().requires_grad_(True)
+        t = tex.cuda().requires_grad_(True) if tex is not None else None
+        rgba = sv3d.soft_rasterize(x, t, img, anti_aliasing=False, texture_type="surface", sigma_val=1e-5,
+                                   gamma_val=1e-2)
+        (rgba * grad).sum().backward()
+        torch.cuda.synchronize()
+        return x.grad.cpu(), (t.grad.cpu() if t is not None else None)
+
+    gb, tb = run(0)
+    gs, ts = run(1)
+    assert gb.abs().max() > 0 and torch.isfinite(gs).all()
+    e = rel_err(gs, gb)
+    et = rel_err(ts, tb) if tb is not None else 0.0
+    _record("large_raster_enumerations_%s" % mode, img=0.0, grad_fv=e, grad_tex=et, unstable=0.0, active=0)
+    assert e < 2e-5 and et < 2e-5, (e, et)
