@@ -85,6 +85,7 @@ struct DevParams {
     float inv_sigma;
     float threshold;              // ln(1/dist_eps - 1) * sigma
     float margin;                 // sqrt(threshold)
+    float visit_threshold;        // squared distance beyond which the forward need not visit a pair
     float l2e_over_gamma;         // log2(e) / gamma
     float inv_gamma;
     float inv_range;              // 1 / (far - near)
@@ -699,7 +700,7 @@ __attribute__((amdgpu_waves_per_eu(MODE == SV3D_TEX_VERTEX8 ? 7 : 8))) void rast
         for (int k = 0; k < 3; ++k) {
             const float c = ey[k] * (px[k] - bcx) - ex[k] * (py[k] - bcy);     // edge function at the centre
             const float v = sgn * c + fabsf(ey[k]) * bhx + fabsf(ex[k]) * bhy;  // its maximum over the block
-            ok = ok && !(v < 0.f && v * v * il[k] > P.threshold);
+            ok = ok && !(v < 0.f && v * v * il[k] > P.visit_threshold);
         }
         return ok;
     };
@@ -1550,6 +1551,16 @@ int make_dev_params(const sv3d_raster_params *p, DevParams &d)
     d.ssum0 = (float)exp((double)p->eps / (double)p->gamma);
     d.inv_S = (float)(1.0 / (double)p->raster_size);
     d.alpha_fast = (double)p->dist_eps / (1.0 - (double)p->dist_eps) < 2.9e-8;   // below half an ulp of 1
+    // The silhouette forward multiplies 1 - D = 1 / (1 + exp(-d2/sigma)) of the outside pairs into a
+    // pixel's product.  From d2 = 17.5 sigma on, exp(-d2/sigma) <= 2.5e-8 is below half an ulp of 1
+    // and the factor is exactly 1.0f: a block that far beyond an edge line of a face is not visited,
+    // although the formula's cull distance (dist_eps = 1e-10: 23 sigma) is larger.  Every pixel still
+    // multiplies the same factors (bit-equal images; where two waves share a block's hits they deal
+    // them out differently, and the product's last bit may move).  The colour modes and the backward
+    // keep the formula's distance: their weights D and gradients D (1 - D) of such pairs are tiny
+    // but not zero.
+    const double exact_one = 17.5 * (double)p->sigma;
+    d.visit_threshold = (d.mode == SV3D_TEX_NONE && d.alpha_fast && exact_one < thr) ? (float)exact_one : d.threshold;
     d.alpha_only = p->alpha_only;
     d.inv_F = p->num_faces == 1 ? 0xffffffffu : (unsigned)(0x100000000ull / (unsigned long long)p->num_faces);
     return SV3D_OK;
