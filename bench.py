@@ -66,6 +66,8 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=3.0, help="budget of the dense silhouette leg")
     ap.add_argument("--no-extras", action="store_true", help="headline only: no api / chamfer / train_step legs")
     ap.add_argument("--train-steps", type=int, default=12, help="timed steps of the train_step leg")
+    ap.add_argument("--extras-limit-s", dest="extras_limit_s", type=float, default=300.0,
+                    help="several ranks: time limit of the extra legs, after which the line is printed without them")
     ap.add_argument("--train-args", default="", help="extra examples/cmr_synthetic.py flags for the train_step leg "
                                                      "(rehearsals with a smaller network)")
     return ap.parse_args()
@@ -377,6 +379,46 @@ def train_step_leg(args, device, world, rank):
             if world > 1 else "none (one rank)"}
 
 
+def run_guarded(run, extras, out, rank, limit_s):
+    """run() on every rank under a time limit; returns when it finished.  If the limit passes first
+    (a rank stuck in a collective cannot be interrupted any other way), rank 0 prints `out` with the
+    legs finished so far and every rank's process ends there with status 0.  If run() raises on
+    rank 0, the line is printed at once, with the error noted; another rank that raises waits for
+    its limit, so that no rank disappears under the others while they may still be communicating."""
+    import threading
+    lock = threading.Lock()
+    state = {"done": False}
+
+    def leave(note):
+        if rank == 0:
+            o = dict(out)
+            o.update(extras)
+            o["extras_error"] = note
+            print(json.dumps(o), flush=True)
+        sys.stdout.flush()
+        os._exit(0)
+
+    def expired():
+        with lock:
+            if not state["done"]:
+                leave(extras.get("extras_error", "the extra legs did not finish within %d s" % limit_s))
+
+    timer = threading.Timer(limit_s, expired)
+    timer.daemon = True
+    timer.start()
+    try:
+        run()
+    except Exception as e:                       # noqa: BLE001 - reported in the line, the headline stands
+        extras["extras_error"] = ("%s: %s" % (type(e).__name__, e))[:600]
+        if rank == 0:
+            with lock:
+                leave(extras["extras_error"])
+        threading.Event().wait()                 # until `expired` ends this process
+    with lock:
+        state["done"] = True
+    timer.cancel()
+
+
 def pmc_traffic(args, kernel):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 counter passes of this same
     command (profiles/pmc_default_workload.json: FETCH_SIZE and WRITE_SIZE in separate passes,
@@ -484,11 +526,15 @@ def main():
             dist.barrier()
 
     extras = {}
-    if not args.no_extras:
-        # own warm-up and timing each; they also leave the GPU busy before the headline starts
+
+    def run_extras():                           # own warm-up and timing each
         extras["api"] = api_leg(args, device, rank)
         extras["chamfer"] = chamfer_leg(device)
         extras["train_step"] = train_step_leg(args, device, world, rank)
+
+    if not args.no_extras and world == 1:
+        # one rank: ahead of the headline, so that they also leave the GPU busy before it starts
+        run_extras()
         gc.collect()
         torch.cuda.empty_cache()
 
@@ -543,8 +589,6 @@ def main():
                                  "fwd_tflops": f_flop / (fwd_ms * 1e-3) / 1e12,
                                  "bwd_tflops": b_flop / (bwd_ms * 1e-3) / 1e12 if bwd_ms > 0 else None}}
 
-    if rank != 0:
-        return
     out = {
         "metric": "SoftRas fwd+bwd images/sec @256^2,1280 faces",
         "value": world * B * K / elapsed,
@@ -567,6 +611,14 @@ def main():
                    "clock_preroll_ms": args.preroll_ms},
         "roofline": roofline,
     }
+    if not args.no_extras and world > 1:
+        # Several ranks: the headline is measured first and the extra legs, whose training step
+        # all-reduces gradients between the ranks, run under a time limit.  A rank that fails or
+        # waits for one that failed must not cost the run its headline: rank 0 then prints the line
+        # with the legs it has and the ranks leave without the group's shutdown handshake.
+        run_guarded(run_extras, extras, out, rank, args.extras_limit_s)
+    if rank != 0:
+        return
     out.update(extras)
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args, fv[0], args.cpu_seconds)

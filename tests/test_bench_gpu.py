@@ -37,3 +37,26 @@ def test_bench_prints_one_json_line_with_roofline_and_cpu_baseline():
     t = j["train_step"]
     assert t["ranks"] == 1 and t["steps"] == 4 and t["dataset_images_per_s"] > 10
     assert t["hip_graph"]["dataset_images_per_s"] > 10 and t["hip_graph"]["ms_per_step"] > 0
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_rehearsal_prints_the_headline_and_the_train_step_under_ddp():
+    """bench.py under torch.distributed.run with two ranks sharing this GPU (gradients through gloo;
+    RCCL wants a GPU per rank) and a small network in the train_step leg: one JSON line from rank 0,
+    headline summed over the ranks, measured before the extra legs, train_step run by both ranks."""
+    env = dict(os.environ, SV3D_DIST_BACKEND="gloo+cuda")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", "29591", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20",
+           "--warmup", "5", "--train-steps", "2", "--extras-limit-s", "200",
+           "--train-args", "--subdivide 1 --img_size 64 --tex_size 2"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=280, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["steps"] == 20 and j["scaling"] == "weak" and "cpu_baseline" not in j
+    assert abs(j["value"] - 2 * 8 * 20 / (j["ms_per_step"] * 20e-3)) < 1e-6 * j["value"]
+    assert "extras_error" not in j, j.get("extras_error")
+    t = j["train_step"]
+    assert t["ranks"] == 2 and t["steps"] == 2 and "2 ranks" in t["gradient_all_reduce"]
+    assert t["dataset_images_per_s"] == pytest.approx(2 * t["dataset_images_per_s_per_rank"])
