@@ -155,6 +155,19 @@ def test_parity_sigma_1e4_config(mode):
     _compare("ico2_sigma1e-4_%s" % mode, fv, tex, 64, False, mode, sigma=1e-4)
 
 
+@pytest.mark.parametrize("mode", ["none", "surface"])
+def test_parity_larger_dist_eps_takes_the_tested_cull(mode):
+    """dist_eps 1e-6 instead of the reference's 1e-10: the cull distance shrinks to sqrt(13.8 sigma) and
+    a fragment at the cull boundary no longer vanishes in fp32 (1 - D = 1 - 1e-6 there), so the
+    silhouette forward evaluates the cull per pair instead of relying on the factor rounding to
+    one, and visits blocks up to the formula's distance.  (A pair within rounding of the boundary
+    moves the result by 1e-6, below the bar.)"""
+    verts, faces = load_mesh(2)
+    fv = camera_space_faces(verts, faces, 2, seed=9)
+    tex = _textures(mode, 2, faces.shape[0], 2)
+    _compare("ico2_dist_eps1e-6_%s" % mode, fv, tex, 64, False, mode, sigma=1e-4, dist_eps=1e-6)
+
+
 @pytest.mark.parametrize("R", [6, 9, 17])
 def test_parity_surface_texture_resolutions(R):
     """The texture backward keeps texel tables in LDS in three layouts: four gradient tables plus
