@@ -32,6 +32,12 @@ namespace {
 #ifndef SV3D_CHAMFER_SMALL_QW
 #define SV3D_CHAMFER_SMALL_QW 2                 // queries per wave of the small-call kernel
 #endif
+#ifndef SV3D_CHAMFER_Q4_MIN
+#define SV3D_CHAMFER_Q4_MIN (4L * 256 * 64 * 4)  // points in the call from which a lane takes four queries
+#endif
+#ifndef SV3D_CHAMFER_Q2_MIN
+#define SV3D_CHAMFER_Q2_MIN (4L * 256 * 64)      // ... two queries (measured: 64 x 642^2 19.4 -> 15.8 us; half of it loses at 32 x 642^2, 8 x 2048^2)
+#endif
 constexpr int kThreads = 256;
 constexpr int kTile = 1024;          // candidates staged per LDS tile (16 KiB)
 constexpr int kGroup = 8;            // candidates per group minimum
@@ -390,7 +396,7 @@ extern "C" int sv3d_chamfer_forward(const float *xyz1, const float *xyz2, int32_
     // Q queries per lane: more reuse of each staged candidate once there is enough work
     // to keep 256 CUs busy with the smaller grid.
     const long total = (long)B * ((long)N + M);
-    const int Q = total >= 4L * 256 * 64 * 4 ? 4 : (total >= 4L * 256 * 64 * 2 ? 2 : 1);
+    const int Q = total >= SV3D_CHAMFER_Q4_MIN ? 4 : (total >= SV3D_CHAMFER_Q2_MIN ? 2 : 1);
     const int per = 64 * Q;
     const int b0 = (N + per - 1) / per, b1 = (M + per - 1) / per;
     dim3 grid(b0 + b1, B), block(kThreads);
