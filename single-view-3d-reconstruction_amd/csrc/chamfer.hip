@@ -38,6 +38,9 @@ namespace {
 #ifndef SV3D_CHAMFER_Q2_MIN
 #define SV3D_CHAMFER_Q2_MIN (4L * 256 * 64)      // ... two queries (measured: 64 x 642^2 19.4 -> 15.8 us; half of it loses at 32 x 642^2, 8 x 2048^2)
 #endif
+#ifndef SV3D_CHAMFER_TINY_WGS
+#define SV3D_CHAMFER_TINY_WGS 512               // sixteen waves per workgroup up to this many workgroups (8 x 2048^2 25.8 -> 21.1 us, 2 x 8192^2 92 -> 73 us; 1024 loses at 32 x 642^2)
+#endif
 constexpr int kThreads = 256;
 constexpr int kTile = 1024;          // candidates staged per LDS tile (16 KiB)
 constexpr int kGroup = 8;            // candidates per group minimum
@@ -400,9 +403,9 @@ extern "C" int sv3d_chamfer_forward(const float *xyz1, const float *xyz2, int32_
     const int per = 64 * Q;
     const int b0 = (N + per - 1) / per, b1 = (M + per - 1) / per;
     dim3 grid(b0 + b1, B), block(kThreads);
-    // at most a workgroup per CU: sixteen waves split every tile, so that the scan of a wave -- the
-    // whole run time of such a call -- is a quarter as long (4 x 642 points: 8.4 -> about 6 us)
-    const bool tiny = (long)(b0 + b1) * B <= 256;
+    // at most two workgroups per CU: sixteen waves split every tile, so that the scan of a wave --
+    // the whole run time of such a call -- is a quarter as long (4 x 642 points: 8.4 -> about 6 us)
+    const bool tiny = (long)(b0 + b1) * B <= SV3D_CHAMFER_TINY_WGS;
     // ... and when both clouds fit the lanes of one wave (16 points each), waves that work alone
     const int cmax = N > M ? N : M;
     if (SV3D_CHAMFER_SMALL && (long)(b0 + b1) * B <= SV3D_CHAMFER_SMALL_WGS && cmax <= 1024) {

@@ -40,7 +40,11 @@ def _check(a, b):
                                    # calls served by the waves-work-alone kernel: every candidate slot
                                    # count (4, 8, 12, 16 per lane) and its edges, odd query counts
                                    (4, 256, 256), (3, 257, 512), (2, 768, 769), (1, 1024, 1023), (16, 642, 100),
-                                   (7, 3, 65), (16, 1024, 1024), (17, 1024, 1024)])
+                                   (7, 3, 65), (16, 1024, 1024), (17, 1024, 1024),
+                                   # the tiled kernel's other forms: four waves with one query per lane
+                                   # (above 512 workgroups), two per lane (from 65536 points per call),
+                                   # four per lane (from 262144)
+                                   (9, 2048, 2048), (52, 642, 642), (33, 2051, 1990), (64, 2048, 2100)])
 def test_forward_random_clouds(B, N, M):
     rng = np.random.default_rng(B * 1000 + N + M)
     _check(rng.standard_normal((B, N, 3)).astype(np.float32),

@@ -15,7 +15,7 @@ dev = torch.device("cuda:0")
 vp = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
 stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
 for B, N, M in [(4, 642, 642), (8, 642, 642), (16, 642, 642), (32, 642, 642), (64, 642, 642), (4, 162, 162), (16, 1024, 1024), (8, 2048, 2048), (64, 2048, 2048), (2, 8192, 8192), (16, 8192, 8192),
-                (64, 2562, 2562)]:
+                (64, 2562, 2562), (32, 642, 642), (4, 2048, 2048), (16, 2048, 2048), (4, 8192, 8192), (8, 2562, 2562)]:
     g = torch.Generator().manual_seed(5)
     a = torch.randn(B, N, 3, generator=g).to(dev)
     b = torch.randn(B, M, 3, generator=g).to(dev)
