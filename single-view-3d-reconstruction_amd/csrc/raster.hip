@@ -1510,7 +1510,10 @@ __global__ __launch_bounds__(kThreads) void raster_backward_kernel(
 // ------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------
-constexpr long kBackwardHalvesMaxFaces = 16384;
+#ifndef SV3D_BWD_HALVES_MAX_FACES
+#define SV3D_BWD_HALVES_MAX_FACES 16384
+#endif
+constexpr long kBackwardHalvesMaxFaces = SV3D_BWD_HALVES_MAX_FACES;
 // -1: the library chooses the backward's pixel enumeration per launch; 0 / 1: whole boxes / row
 // intervals for every launch (tests and tuning, sv3d_raster_backward_spans)
 std::atomic<int> g_backward_spans{-1};
