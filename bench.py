@@ -18,8 +18,10 @@ is the dense fp32 torch evaluation of the same formulas (oracle port) on the hos
 bounded sample, with the other legs of the CPU reference configuration (network forward on one
 256x256 image, dense Chamfer 642 x 642, dense Laplacian) beside it.
 
-Three more objects ride on the same line; they run BEFORE the headline's timed region (their
-own timings, their own warm-up), so the headline starts on a GPU that is already busy:
+Three more objects ride on the same line (their own timings, their own warm-up).  With one rank
+they run BEFORE the headline's timed region, so the headline starts on a GPU that is already busy;
+with several ranks they run after it, under a time limit, and a leg that fails or hangs costs the
+line that leg, not the headline (`extras_error` then says what happened):
   `api`         the same batch through the Python API (`sv3d.render`: camera stage + rasterizer,
                 forward + backward to vertices and cameras), and one `SoftNeuralRenderer` call at
                 the reference's own constants (anti-aliased 512^2 raster, sigma 1e-5)
