@@ -32,6 +32,9 @@ CONFIGS = {
     "c2_rgb": (8, 256, False, 3, 1e-4, "surface", 6),
     "ref_vert8": (64, 256, True, 3, 1e-5, "vertex8", 1),    # eight part maps in one pass
     "ref_mask_b8": (8, 256, True, 3, 1e-5, "none", 1),
+    "ref_mask_b3": (3, 256, True, 3, 1e-5, "none", 1),
+    "ref_rgb_b3": (3, 256, True, 3, 1e-5, "surface", 6),
+    "c2_rgb_b12": (12, 256, False, 3, 1e-4, "surface", 6),
     "ref_rgb_b8": (8, 256, True, 3, 1e-5, "surface", 6),
     "ref_rgb_b16": (16, 256, True, 3, 1e-5, "surface", 6),
     # batch sweep at the benchmark configuration: either side of the kernels' launch-size thresholds
