@@ -246,6 +246,11 @@ def test_no_active_face_shows_background_and_touched_pixels_do_not():
 
 
 def test_bitwise_repeatable_forward_and_backward():
+    """Three runs of the same call give the same bits.  The vertex gradients are register sums with
+    a fixed reduction tree.  The texel gradients of the surface mode are added into wave-private LDS
+    tables with `ds_add_f32`: one wave, program order, and lanes of one instruction that hit the
+    same texel are serialised by the LDS in a fixed lane order -- which is how the hardware behaves
+    and what this test observes, not something the ISA document promises."""
     import sv3d
     verts, faces = load_mesh(2)
     fv = camera_space_faces(verts, faces, 2, seed=21).cuda()
