@@ -29,6 +29,7 @@
 
 #include "camera.h"
 #include "sv3d_hip.h"
+#include "tile_order.h"
 
 #ifdef SV3D_TRACE
 // Diagnostic build only: per-workgroup start / end stamps and phase stamps of the forward kernel.
@@ -560,15 +561,23 @@ __global__ __launch_bounds__(kThreads) void raster_coarse_kernel(
 // ------------------------------------------------------------------------------------
 // Tile of a workgroup's tile number.  Workgroups start in id order and a CU takes the next one as
 // soon as it has room, so the numbering is a schedule.  Small launches (`rings`, even tile counts)
-// number their tiles in square rings from the image centre outwards (ring k holds the 8k + 4 tiles
-// at Chebyshev distance k + 1/2 from the centre): the tiles an object usually covers start first
-// and the empty border is left for the tail.  Large launches lose by that (the heavy tiles then
+// number their tiles from the image centre outwards: the tiles an object usually covers start first
+// and the empty border is left for the tail.  For 4, 8, 16 or 32 tiles a side the order is by the
+// distance of the tile's centre from the image centre (a table, tile_order.h): an object's outline
+// is closer to a circle than to a square, and the corners of a square ring are the emptiest tiles
+// of it.  Other even counts go in square rings (ring k holds the 8k + 4 tiles at Chebyshev
+// distance k + 1/2 from the centre).  Large launches lose by either (the heavy tiles then
 // share their CUs); they go row by row, every tile row rotated by 5 more columns than the row
 // above, so that the tiles one CU receives do not share a screen column.
 __device__ inline void tile_position(int gx, int gy, int tiles_x, bool rings, int &tile_x, int &tile_y)
 {
     // (gx, gy): the workgroup's place in the grid of tiles; its number there is gy * tiles_x + gx
-    if (rings && !(tiles_x & 1)) {
+    if (rings && (tiles_x == 4 || tiles_x == 8 || tiles_x == 16 || tiles_x == 32)) {
+        const int n = gy * tiles_x + gx;                    // 0 <= n < tiles_x^2 by the launch grid
+        const int t = sv3d_dev::kTileOrder[sv3d_dev::tile_order_offset(tiles_x) + (n & (tiles_x * tiles_x - 1))];
+        tile_x = t & (tiles_x - 1);
+        tile_y = t / tiles_x;
+    } else if (rings && !(tiles_x & 1)) {
         const int tile = gy * tiles_x + gx;
         int k = (int)(__builtin_amdgcn_sqrtf((float)tile) * 0.5f);     // raw v_sqrt_f32, corrected below
         if (4 * k * k > tile) --k;

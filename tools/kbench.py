@@ -33,6 +33,10 @@ CONFIGS = {
     "ref_vert8": (64, 256, True, 3, 1e-5, "vertex8", 1),    # eight part maps in one pass
     "ref_mask_b8": (8, 256, True, 3, 1e-5, "none", 1),
     "ref_mask_b3": (3, 256, True, 3, 1e-5, "none", 1),
+    "ref_mask_b2": (2, 256, True, 3, 1e-5, "none", 1),
+    "ref_rgb_b2": (2, 256, True, 3, 1e-5, "surface", 6),
+    "s128_b32": (32, 128, False, 3, 1e-4, "none", 1),
+    "s64_b64": (64, 64, False, 2, 1e-4, "none", 1),
     "ref_rgb_b3": (3, 256, True, 3, 1e-5, "surface", 6),
     "c2_rgb_b12": (12, 256, False, 3, 1e-4, "surface", 6),
     "ref_rgb_b8": (8, 256, True, 3, 1e-5, "surface", 6),
