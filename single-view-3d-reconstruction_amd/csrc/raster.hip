@@ -600,9 +600,13 @@ __device__ inline void tile_position(int gx, int gy, int tiles_x, bool rings, in
 template <int MODE, int SPLIT, bool LO, bool COARSE>
 __global__ __launch_bounds__(kThreads * SPLIT)
 __attribute__((amdgpu_waves_per_eu(MODE == SV3D_TEX_VERTEX8 ? 7 : 8))) void raster_forward_kernel(
-    DevParams P, const float4 *__restrict__ rec, const uint2 *__restrict__ pbox,
-    const uint2 *__restrict__ gbox, const float *__restrict__ tex, float *__restrict__ rgba,
-    float *__restrict__ saved, CoarseBins CB)
+    // The leading arguments are what a wave needs for its first loads (its share of the face boxes,
+    // or the image's group boxes); built with kernel argument preloading they arrive in registers
+    // with the wave, and the loads go out at once instead of after a first trip to memory for the
+    // argument block.  num_faces = P.F.
+    const uint2 *__restrict__ pbox, const uint2 *__restrict__ gbox, int num_faces,
+    const float4 *__restrict__ rec, const float *__restrict__ tex, float *__restrict__ rgba,
+    float *__restrict__ saved, DevParams P, CoarseBins CB)
 {
     // Small launches (SPLIT == 2) are bound by latency, not by instructions: they test every face's
     // pixel box at once (one round trip to memory) instead of the group boxes first and then the
@@ -626,7 +630,7 @@ __attribute__((amdgpu_waves_per_eu(MODE == SV3D_TEX_VERTEX8 ? 7 : 8))) void rast
     const int b = blockIdx.x;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int S = P.S, F = P.F;
+    const int S = P.S, F = num_faces;
     const uint2 *pbox_b = pbox + (size_t)b * F;
     // Small launches send the first box loads of the binning pass out before anything else: the way
     // through the memory system is the longest single wait of a tile, and the tile arithmetic
@@ -1052,9 +1056,12 @@ __device__ inline float wave_sum_lane63(float v)
 // (the host decides from raster size and face count).
 template <int MODE, bool LO, int HALVES, bool SPANS>
 __global__ __launch_bounds__(kThreads) void raster_backward_kernel(
-    DevParams P, const float4 *__restrict__ rec, const uint2 *__restrict__ pbox,
-    const float *__restrict__ tex, const float *__restrict__ saved, const float *__restrict__ grad_rgba,
-    float *__restrict__ gfv, float *__restrict__ gtex)
+    // The leading arguments are what a wave needs to request its face's record; built with kernel
+    // argument preloading they arrive in registers with the wave, and the request goes out at once
+    // instead of after a first trip to memory for the argument block.  nf = B * F; order_batch = B.
+    const float4 *__restrict__ rec, int nf, int order_batch, const float *__restrict__ saved,
+    const float *__restrict__ grad_rgba, const float *__restrict__ tex, const uint2 *__restrict__ pbox,
+    float *__restrict__ gfv, float *__restrict__ gtex, DevParams P)
 {
     extern __shared__ float s_dyn[];            // SURFACE: per wave, texel gradient tables + texel values
 #ifdef SV3D_TRACE
@@ -1069,16 +1076,18 @@ __global__ __launch_bounds__(kThreads) void raster_backward_kernel(
     // Small batches keep the plain order: with one or two images per XCD the images' unequal
     // work would unbalance the XCDs (measured: +1 us at batch 8, -2..5 % from batch 64 on).
     const int nwg = gridDim.x, xcd = blockIdx.x & 7, per = nwg >> 3, rem = nwg & 7;
-    const int wg = P.B >= 32 ? xcd * per + min(xcd, rem) + (blockIdx.x >> 3) : blockIdx.x;
+    const int wg = order_batch >= 32 ? xcd * per + min(xcd, rem) + (blockIdx.x >> 3) : blockIdx.x;
     // global face index b*F + f, and which share of its steps this wave takes
     const int half = HALVES == 2 ? (wave & 1) : 0;
     const int gf_raw = HALVES == 2 ? wg * 2 + (wave >> 1) : wg * 4 + wave;
-    const bool live = gf_raw < P.B * P.F;
+    const bool live = gf_raw < nf;
     if (HALVES == 1 && !live) return;           // whole wave; HALVES == 1 uses no block-level barrier
-    const int gf = live ? gf_raw : P.B * P.F - 1;       // HALVES == 2: idle waves still reach the barrier
-    // Every kernel argument the wave will read is brought into registers in one batch first.
+    const int gf = live ? gf_raw : nf - 1;      // HALVES == 2: idle waves still reach the barrier
+    // The record is requested first, from the preloaded arguments alone; the argument block's other
+    // fields are requested behind it and everything is waited for once.
     // (Not in the eight-channel mode, whose registers leave no room for either: measured +7 % there.)
     constexpr bool kRequestAhead = MODE != SV3D_TEX_VERTEX8;
+    const FaceRec r = kRequestAhead ? load_rec_uniform(rec + (size_t)gf * kRec4) : load_rec(rec + (size_t)gf * kRec4);
     if (kRequestAhead)
         asm volatile("" ::"s"(P.S), "s"(P.aa), "s"(P.TB), "s"(P.inv_S), "s"(P.inv_F), "s"(P.alpha_only), "s"(P.R),
                      "s"(P.threshold), "s"(P.neg_l2e_over_sigma), "s"(P.inv_sigma), "s"(saved), "s"(grad_rgba),
@@ -1100,7 +1109,6 @@ __global__ __launch_bounds__(kThreads) void raster_backward_kernel(
     const float *grad_b = grad_rgba + (size_t)b * (only_alpha ? 1 : NC + 1) * plane;
     const float *grad_alpha = grad_b + (only_alpha ? 0 : NC * plane);      // alpha plane of image b
     const float fS = (float)S;
-    const FaceRec r = kRequestAhead ? load_rec_uniform(rec + (size_t)gf * kRec4) : load_rec(rec + (size_t)gf * kRec4);
     int col0, col1, row0, row1;
     unpack_box(make_uint2(r.box_x, r.box_y), col0, col1, row0, row1);
     const int bw = col1 - col0 + 1, bh = row1 - row0 + 1;
@@ -1681,8 +1689,8 @@ int raster_forward_impl(const sv3d_raster_params *p, const float *face_vertices,
     const bool lo = (d.S & (d.S - 1)) != 0;
     const dim3 grid3((unsigned)d.B, (unsigned)tiles, (unsigned)tiles);  // tiles <= 256, batch <= 65535
 #define SV3D_LAUNCH_FWD2(M, SP, LO_, CO_)                                                              \
-    hipLaunchKernelGGL((raster_forward_kernel<M, SP, LO_, CO_>), grid3, dim3(SP * kThreads), 0, s, d, rec, \
-                       pbox, gbox, textures, rgba_out, saved, cb)
+    hipLaunchKernelGGL((raster_forward_kernel<M, SP, LO_, CO_>), grid3, dim3(SP * kThreads), 0, s, pbox,   \
+                       gbox, d.F, rec, textures, rgba_out, saved, d, cb)
 #define SV3D_LAUNCH_FWD(M)                                                                             \
     do {                                                                                               \
         if (coarse && lo) SV3D_LAUNCH_FWD2(M, 1, true, true);                                          \
@@ -1730,8 +1738,8 @@ int raster_backward_impl(const sv3d_raster_params *p, const float *textures, con
     const int forced = g_backward_spans.load(std::memory_order_relaxed);
     const bool spans = forced < 0 ? (long)d.S * d.S >= 64L * d.F : forced != 0;
 #define SV3D_BWD_CASE(M, LO_, H_, SP_)                                                                  \
-    hipLaunchKernelGGL((raster_backward_kernel<M, LO_, H_, SP_>), fgrid, block, lds, s, d, rec, pbox,   \
-                       textures, saved, grad_rgba, grad_face_vertices, gt)
+    hipLaunchKernelGGL((raster_backward_kernel<M, LO_, H_, SP_>), fgrid, block, lds, s, rec, d.B * d.F,  \
+                       d.B, saved, grad_rgba, textures, pbox, grad_face_vertices, gt, d)
 #define SV3D_BWD_SPANS(M, SP_)                                                                          \
     do {                                                                                                \
         if (lo && halves) SV3D_BWD_CASE(M, true, 2, SP_);                                               \

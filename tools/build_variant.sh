@@ -12,7 +12,7 @@ done
 mkdir -p gpurun_variants/obj
 make -s -C $src >/dev/null
 /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -fno-slp-vectorize --offload-arch=gfx950 -Iinclude -I$src -Wall -Wno-unused-function \
-  "${flags[@]}" -c $raster -o gpurun_variants/obj/$name.raster.o
+  -mllvm -amdgpu-kernarg-preload-count=16 "${flags[@]}" -c $raster -o gpurun_variants/obj/$name.raster.o
 /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o gpurun_variants/$name.so gpurun_variants/obj/$name.raster.o \
   $src/build/chamfer.hip.o $src/build/mesh.hip.o $src/build/meshreg.hip.o $src/build/texture.hip.o $src/build/abi.cpp.o
 echo gpurun_variants/$name.so
