@@ -23,6 +23,7 @@
 // amplification acts on a small, exactly representable offset.
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include <stddef.h>
 #include <stdint.h>
 
 #include <atomic>
@@ -96,6 +97,23 @@ struct DevParams {
     int alpha_only;               // silhouette mode: the image (and its gradient) is the alpha plane alone
     unsigned inv_F;               // floor(2^32 / F): the image of a face index by a multiply, see image_of_face
 };
+
+// A parameter block read field by field from constant memory (the argument block of a kernel);
+// fields the caller never uses are never loaded.
+typedef const DevParams __attribute__((address_space(4))) *ConstantParams;
+__device__ inline DevParams copy_params(ConstantParams p)
+{
+    DevParams d;
+    d.B = p->B; d.F = p->F; d.S = p->S; d.aa = p->aa; d.mode = p->mode; d.R = p->R; d.double_side = p->double_side;
+    d.TB = p->TB;
+    d.bg0 = p->bg0; d.bg1 = p->bg1; d.bg2 = p->bg2;
+    d.near_plane = p->near_plane; d.far_plane = p->far_plane; d.eps = p->eps;
+    d.neg_l2e_over_sigma = p->neg_l2e_over_sigma; d.inv_sigma = p->inv_sigma; d.threshold = p->threshold;
+    d.margin = p->margin; d.visit_threshold = p->visit_threshold; d.l2e_over_gamma = p->l2e_over_gamma;
+    d.inv_gamma = p->inv_gamma; d.inv_range = p->inv_range; d.ssum0 = p->ssum0; d.inv_S = p->inv_S;
+    d.alpha_fast = p->alpha_fast; d.alpha_only = p->alpha_only; d.inv_F = p->inv_F;
+    return d;
+}
 
 // b = gf / F for 0 <= gf < B * F <= 2^29, without the ~25 instructions of an integer division (the
 // backward's waves start with it, eight to a SIMD): the multiply gives gf / F or one less.
@@ -1054,14 +1072,28 @@ __device__ inline float wave_sum_lane63(float v)
 // pixel row only the interval of columns that can hold an active pixel (below).  Finding a lane's
 // row then costs a short search per step, which pays once the faces are large enough in pixels
 // (the host decides from raster size and face count).
+// The backward kernel's arguments as a struct: the argument block of a kernel is laid out like one
+// (every argument at its natural alignment, in order), which gives the offset of the parameter
+// block that the kernel reads through the block's address.
+struct BackwardArgsLayout {
+    const void *rec; int nf, order_batch; const void *saved, *grad_rgba;
+    int S, aa, alpha_only, F; unsigned inv_F; float inv_S;
+    const void *tex, *pbox; void *gfv, *gtex;
+    DevParams P;
+};
+static_assert(offsetof(BackwardArgsLayout, tex) == 56, "the preloaded arguments are the first 14 dwords");
+
 template <int MODE, bool LO, int HALVES, bool SPANS>
 __global__ __launch_bounds__(kThreads) void raster_backward_kernel(
-    // The leading arguments are what a wave needs to request its face's record; built with kernel
-    // argument preloading they arrive in registers with the wave, and the request goes out at once
-    // instead of after a first trip to memory for the argument block.  nf = B * F; order_batch = B.
+    // The leading 14 dwords are what a wave needs to request its face's record and, once that is
+    // there, its first pixels; built with kernel argument preloading they arrive in registers with
+    // the wave: the record request goes out at once instead of after a first trip to memory for
+    // the argument block.  nf = B * F; order_batch = B; S_ .. inv_S_ repeat fields of the
+    // parameter block, which is requested together with the first pixels (below).
     const float4 *__restrict__ rec, int nf, int order_batch, const float *__restrict__ saved,
-    const float *__restrict__ grad_rgba, const float *__restrict__ tex, const uint2 *__restrict__ pbox,
-    float *__restrict__ gfv, float *__restrict__ gtex, DevParams P)
+    const float *__restrict__ grad_rgba, int S_, int aa_, int alpha_only_, int F_, unsigned inv_F_, float inv_S_,
+    const float *__restrict__ tex, const uint2 *__restrict__ pbox, float *__restrict__ gfv,
+    float *__restrict__ gtex, DevParams P_block)
 {
     extern __shared__ float s_dyn[];            // SURFACE: per wave, texel gradient tables + texel values
 #ifdef SV3D_TRACE
@@ -1083,28 +1115,35 @@ __global__ __launch_bounds__(kThreads) void raster_backward_kernel(
     const bool live = gf_raw < nf;
     if (HALVES == 1 && !live) return;           // whole wave; HALVES == 1 uses no block-level barrier
     const int gf = live ? gf_raw : nf - 1;      // HALVES == 2: idle waves still reach the barrier
-    // The record is requested first, from the preloaded arguments alone; the argument block's other
-    // fields are requested behind it and everything is waited for once.
-    // (Not in the eight-channel mode, whose registers leave no room for either: measured +7 % there.)
+    // The record is requested first, from the preloaded arguments alone, and waited for.
+    // (The eight-channel mode, whose registers leave no room for a record in scalar registers across
+    // the arithmetic, reads it with vector loads: measured +7 % otherwise.)
     constexpr bool kRequestAhead = MODE != SV3D_TEX_VERTEX8;
     const FaceRec r = kRequestAhead ? load_rec_uniform(rec + (size_t)gf * kRec4) : load_rec(rec + (size_t)gf * kRec4);
-    if (kRequestAhead)
-        asm volatile("" ::"s"(P.S), "s"(P.aa), "s"(P.TB), "s"(P.inv_S), "s"(P.inv_F), "s"(P.alpha_only), "s"(P.R),
-                     "s"(P.threshold), "s"(P.neg_l2e_over_sigma), "s"(P.inv_sigma), "s"(saved), "s"(grad_rgba),
-                     "s"(tex));
+    // The parameter block is read through the address of the argument block.  Left to the
+    // compiler, its loads are issued ahead of the record request and, a register of theirs being
+    // reused, waited for before it: a trip to memory in front of the record's.  The address is
+    // therefore made to depend on the record (an empty statement the compiler cannot see
+    // through): the block's loads then go out behind the record, alongside the first pixel loads,
+    // which need none of it -- what they need repeats in the preloaded arguments.
+    typedef const char __attribute__((address_space(4))) *ConstantBytes;
+    ConstantBytes kargs = (ConstantBytes)__builtin_amdgcn_kernarg_segment_ptr();
+    if (kRequestAhead) asm volatile("" : "+s"(kargs) : "s"(r.flags));
+    const DevParams P = copy_params((ConstantParams)(kargs + offsetof(BackwardArgsLayout, P)));
+    (void)P_block;
     // The pixel box is taken from the record (floats 28..29), not from the compact box array: one
     // request, one wait, then the pixel loads can go out.
-    const int b = image_of_face(gf, P.F, P.inv_F);
-    const int tgf = P.TB == P.B ? gf : gf - (b - b % P.TB) * P.F;     // the face in its texture set
-    const int S = P.S;
+    const int b = image_of_face(gf, F_, inv_F_);
+    const int tgf = P.TB == P.B ? gf : gf - (b - b % P.TB) * F_;      // the face in its texture set
+    const int S = S_;
     constexpr int NC = mode_channels(MODE);     // colour channels
     constexpr int PP = MODE == SV3D_TEX_NONE ? 1 : (NC == 3 ? 6 : 12);   // saved floats per pixel
-    const float step = 2.f * P.inv_S;
+    const float step = 2.f * inv_S_;
     const float *saved_b = saved + (size_t)b * S * S * PP;
-    const int H = P.aa == 2 ? S >> 1 : S;
-    const float gscale = P.aa == 2 ? 0.25f : 1.f;
+    const int H = aa_ == 2 ? S >> 1 : S;
+    const float gscale = aa_ == 2 ? 0.25f : 1.f;
     const size_t plane = (size_t)H * H;
-    const bool only_alpha = MODE == SV3D_TEX_NONE && P.alpha_only;
+    const bool only_alpha = MODE == SV3D_TEX_NONE && alpha_only_;
     // colour + alpha planes of image b, or its alpha plane alone
     const float *grad_b = grad_rgba + (size_t)b * (only_alpha ? 1 : NC + 1) * plane;
     const float *grad_alpha = grad_b + (only_alpha ? 0 : NC * plane);      // alpha plane of image b
@@ -1163,7 +1202,7 @@ __global__ __launch_bounds__(kThreads) void raster_backward_kernel(
     // their latency overlaps the arithmetic.
     const float bw_f = (float)bw, bh_f = (float)bh;
     float xp0, yp0;
-    pixel_centre(col0, row0, S, P.inv_S, xp0, yp0);
+    pixel_centre(col0, row0, S, inv_S_, xp0, yp0);
     constexpr int kStride = 64 * HALVES;        // pixel numbers between two steps of one wave
     const int rows_live = npix > 0 ? bh : 0;
     float adv_x = 0.f, adv_y = 0.f, rx_f = 0.f, ry_f = 0.f;
@@ -1256,15 +1295,15 @@ __global__ __launch_bounds__(kThreads) void raster_backward_kernel(
         in.xp = fmaf(cx, step, xp0);
         in.yp = fmaf(-cy, step, yp0);
         if (LO) {           // remainder of the exact centre over the rounded one, see struct Pixel
-            in.xl = fmaf(-in.xp, fS, fmaf(2.f, cx, kx0)) * P.inv_S;
-            in.yl = fmaf(-in.yp, fS, fmaf(-2.f, cy, ky0)) * P.inv_S;
+            in.xl = fmaf(-in.xp, fS, fmaf(2.f, cx, kx0)) * inv_S_;
+            in.yl = fmaf(-in.yp, fS, fmaf(-2.f, cy, ky0)) * inv_S_;
         } else {
             in.xl = in.yl = 0.f;
         }
         const unsigned prow = (unsigned)(row0 + (int)cy), pcol = (unsigned)(col0 + (int)cx);
         // rows, columns and sizes are at most 4096: 24-bit multiplies (one v_mad_u32_u24 each)
         const unsigned pix = __umul24(prow, (unsigned)S) + pcol;
-        const unsigned gpix = P.aa == 2 ? __umul24(prow >> 1, (unsigned)H) + (pcol >> 1) : pix;
+        const unsigned gpix = aa_ == 2 ? __umul24(prow >> 1, (unsigned)H) + (pcol >> 1) : pix;
         in.ssum = in.m = 0.f;
 #pragma unroll
         for (int c = 0; c < NC; ++c) in.col[c] = in.gch[c] = 0.f;
@@ -1333,6 +1372,10 @@ __global__ __launch_bounds__(kThreads) void raster_backward_kernel(
     }
     PixIn nxt;
     if (span_total > half * 64) nxt = fetch(half * 64);
+    // The parameter block read through the argument block's address must be the one the preloaded
+    // arguments repeat.  It is, unless the kernel's argument list and BackwardArgsLayout part ways:
+    // then every wave of the launch leaves here, nothing is written, and the parity tests fail.
+    if (P.S != S_ || P.F != F_ || P.inv_F != inv_F_) return;
 #ifdef SV3D_TRACE
     if (rg == 0) {
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     // the first pixels are here
@@ -1739,7 +1782,8 @@ int raster_backward_impl(const sv3d_raster_params *p, const float *textures, con
     const bool spans = forced < 0 ? (long)d.S * d.S >= 64L * d.F : forced != 0;
 #define SV3D_BWD_CASE(M, LO_, H_, SP_)                                                                  \
     hipLaunchKernelGGL((raster_backward_kernel<M, LO_, H_, SP_>), fgrid, block, lds, s, rec, d.B * d.F,  \
-                       d.B, saved, grad_rgba, textures, pbox, grad_face_vertices, gt, d)
+                       d.B, saved, grad_rgba, d.S, d.aa, d.alpha_only, d.F, d.inv_F, d.inv_S, textures, pbox,  \
+                       grad_face_vertices, gt, d)
 #define SV3D_BWD_SPANS(M, SP_)                                                                          \
     do {                                                                                                \
         if (lo && halves) SV3D_BWD_CASE(M, true, 2, SP_);                                               \

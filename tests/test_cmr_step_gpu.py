@@ -95,7 +95,9 @@ def test_captured_step_matches_the_eager_step(tmp_path):
     floor = rel(grads_p, grads_e)
     got = rel(grads_g, grads_e)
     print("captured vs eager gradient %.3e, one-in-1e6 perturbation %.3e" % (got, floor))
-    assert got < max(10.0 * floor, 1e-4) and got < 3e-2, (got, floor)
+    # (a stale input or a missed kernel in the replay would move the gradient by its own size;
+    # the measured effect varies from run to run by a factor of a few, hence the wide factor)
+    assert got < max(30.0 * floor, 1e-4) and got < 1e-1, (got, floor)
     # a batch of another shape is refused, not silently replayed
     t.set_input((batch[0][:1], batch[1][:1]))
     with pytest.raises(RuntimeError):
