@@ -320,6 +320,8 @@ def train_step_leg(args, device, world, rank):
     """examples/cmr_synthetic.py's step (encoder, camera hypotheses, shared render passes, part maps,
     Chamfer, regularisers, distance-map loss, autocast + clip + fused Adam x2) at batch 4 per rank."""
     import tempfile
+    if os.environ.get("SV3D_BENCH_FAIL_RANK") == str(rank):
+        raise RuntimeError("SV3D_BENCH_FAIL_RANK: this rank was asked to fail in the train_step leg")
     cmr = _load_cmr_module()
     tmp = tempfile.mkdtemp(prefix="sv3d_bench_")
     o = cmr.parse(["--batch_size", "4", "--seg_train", "1", "--print_scalars", "0", "--checkpoint_dir", tmp,
@@ -330,8 +332,11 @@ def train_step_leg(args, device, world, rank):
     env = train_utils.init_distributed(gpu_id=device.index)
     t = cmr.ShapeTrainer(o, env)
     t.init_training()
+    note("train_step: trainer built (%d parameters%s)"
+         % (sum(p.numel() for p in t.model.parameters()), ", DDP over %d ranks" % world if world > 1 else ""))
     o.num_iter = 6                                   # warm-up: library start-up, autotuning, allocator
     t.train()
+    note("train_step: 6 warm-up steps done")
     o.num_iter = args.train_steps
     if world > 1:
         torch.distributed.barrier()
@@ -381,44 +386,106 @@ def train_step_leg(args, device, world, rank):
             if world > 1 else "none (one rank)"}
 
 
-def run_guarded(run, extras, out, rank, limit_s):
-    """run() on every rank under a time limit; returns when it finished.  If the limit passes first
-    (a rank stuck in a collective cannot be interrupted any other way), rank 0 prints `out` with the
-    legs finished so far and every rank's process ends there with status 0.  If run() raises on
-    rank 0, the line is printed at once, with the error noted; another rank that raises waits for
-    its limit, so that no rank disappears under the others while they may still be communicating."""
+_T0 = time.perf_counter()
+
+
+def note(msg):
+    """Progress line on stderr (rank, seconds since start): what a run that ends in a time limit was
+    doing, and where its time went."""
+    sys.stderr.write("[bench rank %s +%.1fs] %s\n" % (os.environ.get("RANK", "0"), time.perf_counter() - _T0, msg))
+    sys.stderr.flush()
+
+
+FAILED_KEY = "sv3d_bench_extras_failed"
+
+
+def _group_store():
+    """The process group's key-value store (None outside a process group)."""
+    try:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            return dist.distributed_c10d._get_default_store()
+    except Exception:                            # noqa: BLE001 - diagnostics only
+        pass
+    return None
+
+
+def run_guarded(run, extras, out, rank, limit_s, poll_s=1.0):
+    """run() on every rank under a time limit; returns when it finished.
+
+    A rank whose run() raises writes the exception and its traceback to stderr at once and posts it
+    in the process group's store; every rank's watcher thread polls that key, so rank 0 prints `out`
+    with the legs finished so far and `extras_error` = "rank R: Error: text" within a second, and
+    all ranks end there with status 0 (a rank waiting in a collective for the one that failed cannot
+    be interrupted any other way).  If the limit passes with nothing posted, every rank first dumps
+    the Python stack of each of its threads to stderr -- which collective or call it is stuck in --
+    and rank 0 prints the line with a "did not finish" note."""
+    import faulthandler
     import threading
+    import traceback
     lock = threading.Lock()
     state = {"done": False}
+    store = _group_store()
+    t_end = time.monotonic() + limit_s
 
-    def leave(note):
+    def leave(note_text):
         if rank == 0:
             o = dict(out)
-            o.update(extras)
-            o["extras_error"] = note
+            o.update({k: v for k, v in extras.items() if not k.startswith("_")})
+            o["extras_error"] = note_text
             print(json.dumps(o), flush=True)
         sys.stdout.flush()
+        sys.stderr.flush()
         os._exit(0)
 
-    def expired():
-        with lock:
-            if not state["done"]:
-                leave(extras.get("extras_error", "the extra legs did not finish within %d s" % limit_s))
+    def posted():
+        if store is None:
+            return None
+        try:
+            if store.check([FAILED_KEY]):
+                return store.get(FAILED_KEY).decode("utf-8", "replace")
+        except Exception:                        # noqa: BLE001 - the store went away with its rank
+            return None
+        return None
 
-    timer = threading.Timer(limit_s, expired)
-    timer.daemon = True
-    timer.start()
+    def watch():
+        while True:
+            time.sleep(min(poll_s, max(t_end - time.monotonic(), 0.0)) or 0.01)
+            with lock:
+                if state["done"]:
+                    return
+                msg = posted()
+                if msg is not None:
+                    note("leaving the extra legs: " + msg)
+                    leave(msg)
+                if time.monotonic() >= t_end:
+                    note("the extra legs did not finish within %d s (last: %s); stacks of all threads follow"
+                         % (limit_s, extras.get("_leg", "?")))
+                    faulthandler.dump_traceback(file=sys.stderr, all_threads=True)
+                    leave(extras.get("extras_error", "the extra legs did not finish within %d s (rank %d was in: %s)"
+                                     % (limit_s, rank, extras.get("_leg", "?"))))
+
+    watcher = threading.Thread(target=watch, daemon=True)
+    watcher.start()
     try:
         run()
     except Exception as e:                       # noqa: BLE001 - reported in the line, the headline stands
-        extras["extras_error"] = ("%s: %s" % (type(e).__name__, e))[:600]
+        text = ("rank %d: %s: %s" % (rank, type(e).__name__, e))[:600]
+        note("rank %d: an extra leg raised (%s):\n%s" % (rank, extras.get("_leg", "?"), traceback.format_exc()))
+        extras["extras_error"] = text
+        if store is not None:
+            try:
+                store.set(FAILED_KEY, text)
+            except Exception:                    # noqa: BLE001
+                pass
         if rank == 0:
             with lock:
-                leave(extras["extras_error"])
-        threading.Event().wait()                 # until `expired` ends this process
+                extras.pop("_leg", None)
+                leave(text)
+        threading.Event().wait()                 # until the watcher ends this process
     with lock:
         state["done"] = True
-    timer.cancel()
+    extras.pop("_leg", None)
 
 
 def pmc_traffic(args, kernel):
@@ -440,11 +507,13 @@ def pmc_traffic(args, kernel):
 
 def main():
     args = parse()
-    if os.environ.get("SV3D_BENCH_WATCHDOG"):
-        # diagnostic: dump every thread's Python stack to stderr if the run is still going after N seconds
-        import faulthandler
-        faulthandler.dump_traceback_later(float(os.environ["SV3D_BENCH_WATCHDOG"]), repeat=False)
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # diagnostic: every thread's Python stack on stderr if the run is still going after N seconds
+    # (several ranks: armed by default at 0.8 of the extra legs' limit, counted from the start)
+    watchdog = os.environ.get("SV3D_BENCH_WATCHDOG") or (str(0.8 * args.extras_limit_s) if world > 1 else "")
+    if watchdog and float(watchdog) > 0:
+        import faulthandler
+        faulthandler.dump_traceback_later(float(watchdog), repeat=False)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
@@ -530,9 +599,13 @@ def main():
     extras = {}
 
     def run_extras():                           # own warm-up and timing each
-        extras["api"] = api_leg(args, device, rank)
-        extras["chamfer"] = chamfer_leg(device)
-        extras["train_step"] = train_step_leg(args, device, world, rank)
+        for name, leg in (("api", lambda: api_leg(args, device, rank)), ("chamfer", lambda: chamfer_leg(device)),
+                          ("train_step", lambda: train_step_leg(args, device, world, rank))):
+            extras["_leg"] = name
+            note("leg %s starts" % name)
+            extras[name] = leg()
+            note("leg %s done" % name)
+        extras.pop("_leg", None)
 
     if not args.no_extras and world == 1:
         # one rank: ahead of the headline, so that they also leave the GPU busy before it starts
@@ -621,7 +694,7 @@ def main():
         run_guarded(run_extras, extras, out, rank, args.extras_limit_s)
     if rank != 0:
         return
-    out.update(extras)
+    out.update({k: v for k, v in extras.items() if not k.startswith("_")})
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args, fv[0], args.cpu_seconds)
     print(json.dumps(out), flush=True)

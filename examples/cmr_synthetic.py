@@ -57,19 +57,22 @@ class BasicBlock(nn.Module):
 
 
 class Encoder(nn.Module):
-    """ResNet-18 trunk -> 200-d code (mesh_net.py:155-208 in shape)."""
+    """ResNet-18 trunk -> 200-d code (mesh_net.py:155-208 in shape).  `width` is the channel count
+    of the first stage (64 in ResNet-18: 11 M parameters; 8 gives 0.2 M, for rehearsals whose
+    gradients travel through the host)."""
 
-    def __init__(self, nz=200):
+    def __init__(self, nz=200, width=64):
         super().__init__()
-        self.stem = nn.Sequential(nn.Conv2d(3, 64, 7, 2, 3, bias=False), nn.BatchNorm2d(64), nn.ReLU(True),
+        w = width
+        self.stem = nn.Sequential(nn.Conv2d(3, w, 7, 2, 3, bias=False), nn.BatchNorm2d(w), nn.ReLU(True),
                                   nn.MaxPool2d(3, 2, 1))
-        cfg, layers, cin = [(64, 1), (128, 2), (256, 2), (512, 2)], [], 64
+        cfg, layers, cin = [(w, 1), (2 * w, 2), (4 * w, 2), (8 * w, 2)], [], w
         for cout, stride in cfg:
             layers += [BasicBlock(cin, cout, stride), BasicBlock(cout, cout, 1)]
             cin = cout
         self.layers = nn.Sequential(*layers)
-        self.squeeze = nn.Sequential(nn.Conv2d(512, 256, 4, 2, 1), nn.BatchNorm2d(256), nn.LeakyReLU(0.2, True))
-        self.fc = nn.Sequential(nn.Linear(256 * 4 * 4, nz), nn.BatchNorm1d(nz), nn.LeakyReLU(0.2, True),
+        self.squeeze = nn.Sequential(nn.Conv2d(8 * w, 4 * w, 4, 2, 1), nn.BatchNorm2d(4 * w), nn.LeakyReLU(0.2, True))
+        self.fc = nn.Sequential(nn.Linear(4 * w * 4 * 4, nz), nn.BatchNorm1d(nz), nn.LeakyReLU(0.2, True),
                                 nn.Linear(nz, nz), nn.BatchNorm1d(nz), nn.LeakyReLU(0.2, True))
 
     def forward(self, img):
@@ -79,12 +82,12 @@ class Encoder(nn.Module):
 
 
 class MeshNetLite(nn.Module):
-    def __init__(self, verts, faces, num_cams=8, tex_size=6, nz=200):
+    def __init__(self, verts, faces, num_cams=8, tex_size=6, nz=200, enc_width=64):
         super().__init__()
         self.num_cams, self.tex_size = num_cams, tex_size
         self.register_buffer("mean_v", verts)
         self.register_buffer("faces", faces)
-        self.encoder = Encoder(nz)
+        self.encoder = Encoder(nz, enc_width)
         self.shape = nn.Linear(nz, verts.shape[0] * 3)
         nn.init.normal_(self.shape.weight, std=1e-4)
         self.cam = nn.Linear(nz, num_cams * 7)
@@ -212,7 +215,7 @@ class ShapeTrainer(train_utils.Trainer):
         o = self.opts
         verts, faces = meshgen.icosphere(o.subdivide)
         verts, faces = torch.from_numpy(verts), torch.from_numpy(faces)
-        self.model = MeshNetLite(verts, faces.long(), o.num_hypo_cams, o.tex_size)
+        self.model = MeshNetLite(verts, faces.long(), o.num_hypo_cams, o.tex_size, enc_width=o.enc_width)
         if o.channels_last:
             self.model = self.model.to(memory_format=torch.channels_last)
         self.part_basis_generator = PartBasisGenerator(verts.shape[0], o.num_parts)
@@ -299,6 +302,8 @@ def parse(argv=None):
     p.add_argument('--img_size', type=int, default=256)
     p.add_argument('--subdivide', type=int, default=3)
     p.add_argument('--tex_size', type=int, default=6)
+    p.add_argument('--enc_width', type=int, default=64,
+                   help="channels of the encoder's first stage (64 = ResNet-18; smaller for rehearsals)")
     p.add_argument('--num_hypo_cams', type=int, default=8)
     p.add_argument('--num_parts', type=int, default=8)
     p.add_argument('--chamf_loss_wt', type=float, default=1.0)

@@ -48,7 +48,7 @@ def test_bench_two_ranks_rehearsal_prints_the_headline_and_the_train_step_under_
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", "29591", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20",
            "--warmup", "5", "--train-steps", "2", "--extras-limit-s", "200",
-           "--train-args", "--subdivide 1 --img_size 64 --tex_size 2"]
+           "--train-args", "--subdivide 1 --img_size 64 --tex_size 2 --enc_width 8"]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=280, env=env, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.strip().startswith("{")]
@@ -56,7 +56,7 @@ def test_bench_two_ranks_rehearsal_prints_the_headline_and_the_train_step_under_
     j = json.loads(lines[0])
     assert j["n_gpus"] == 2 and j["steps"] == 20 and j["scaling"] == "weak" and "cpu_baseline" not in j
     assert abs(j["value"] - 2 * 8 * 20 / (j["ms_per_step"] * 20e-3)) < 1e-6 * j["value"]
-    assert "extras_error" not in j, j.get("extras_error")
+    assert "extras_error" not in j, "%s\n--- stderr of the ranks ---\n%s" % (j.get("extras_error"), out.stderr[-6000:])
     t = j["train_step"]
     assert t["ranks"] == 2 and t["steps"] == 2 and "2 ranks" in t["gradient_all_reduce"]
     assert t["dataset_images_per_s"] == pytest.approx(2 * t["dataset_images_per_s_per_rank"])
