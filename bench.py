@@ -12,13 +12,15 @@ the same size -- the path shards by image with no data-path collective -- so sca
 weak and `value` is the sum over ranks.
 
 Prints ONE JSON line (rank 0).  `roofline` is for the kernel with the longest average
-launch (FP32 VALU bound; timed with HIP events recorded on the launch stream around that
-kernel on every 10th timed step, every 4th of runs shorter than 100 steps).  `cpu_baseline`
+launch (FP32 VALU bound).  Kernel durations come from a separate pass AFTER the timed region:
+60 launches per kernel, HIP events recorded on the launch stream around batches of 10 launches
+of that kernel alone (an event pair costs microseconds of stream time, which a 17 us kernel
+cannot carry: the timed region itself carries no events).  `cpu_baseline`
 is the dense fp32 torch evaluation of the same formulas (oracle port) on the host cores, on a
 bounded sample, with the other legs of the CPU reference configuration (network forward on one
 256x256 image, dense Chamfer 642 x 642, dense Laplacian) beside it.
 
-Three more objects ride on the same line (their own timings, their own warm-up).  With one rank
+Four more objects ride on the same line (their own timings, their own warm-up).  With one rank
 they run BEFORE the headline's timed region, so the headline starts on a GPU that is already busy;
 with several ranks they run after it, under a time limit, and a leg that fails or hangs costs the
 line that leg, not the headline (`extras_error` then says what happened):
@@ -29,8 +31,14 @@ line that leg, not the headline (`extras_error` then says what happened):
                 fraction of the FP32 vector peak (16 B N M flop per call)
   `train_step`  the synthetic CMR-style training step of examples/cmr_synthetic.py at the
                 reference's default batch (4 dataset images -> 64 rendered images per pass):
-                dataset images/s per rank and summed; with N > 1 the step runs under
-                DistributedDataParallel, so its gradients are all-reduced by RCCL
+                dataset images/s per rank and summed; with N > 1 (or --force-dist) the step runs
+                under DistributedDataParallel, so its gradients are all-reduced by RCCL.  One
+                rank also runs the step on the 5120-face mesh and the batch-64 reading of the
+                full-step configuration (64 dataset images, one camera hypothesis, no mirror pair)
+  `configs`     the larger configurations through the C ABI, forward + backward, 64 images each:
+                surface RGB on the 5120-face mesh (T = 6, anti-aliased 512^2 raster), eight part
+                maps in one pass at the reference defaults, and Chamfer 16 x 8192^2 forward +
+                backward; images/s (clouds/s) and the dominant kernel's fraction of the FP32 peak
 """
 import argparse
 import ctypes
@@ -58,8 +66,10 @@ def parse():
     ap.add_argument("--sigma", type=float, default=1e-4)
     ap.add_argument("--preroll-ms", dest="preroll_ms", type=float, default=80.0,
                     help="untimed repetition of the step before the warm-up steps, to bring the clocks up")
-    ap.add_argument("--event_stride", type=int, default=10,
-                    help="record HIP events around the kernels on every n-th timed step")
+    ap.add_argument("--kernel-launches", dest="kernel_launches", type=int, default=60,
+                    help="launches per kernel in the kernel-duration pass after the timed region (batches of 10)")
+    ap.add_argument("--force-dist", dest="force_dist", action="store_true",
+                    help="one rank: open the RCCL process group and wrap the train step in DDP anyway")
     ap.add_argument("--gamma", type=float, default=1e-4)
     ap.add_argument("--mode", choices=["none", "surface", "vertex"], default="none")
     ap.add_argument("--tex-size", type=int, default=6)
@@ -96,6 +106,10 @@ class HipEvents:
             out.append(e)
         return out
 
+    def destroy(self, events):
+        for e in events:
+            self.hip.hipEventDestroy(e)
+
     def elapsed_ms(self, a, b):
         ms = ctypes.c_float()
         if self.hip.hipEventElapsedTime(ctypes.byref(ms), a, b) != 0:
@@ -122,6 +136,8 @@ def build_inputs(args, device, seed):
                           shift=(0.0, 0.0, 2.732))
     H = args.image_size
     grad = (2 * torch.rand(B, 4, H, H, generator=g) - 1).to(device)
+    if args.mode == "none" and getattr(args, "alpha_only", False):
+        grad = grad[:, 3:4]                     # the silhouette caller's gradient: the alpha plane alone
     tex = None
     if args.mode == "surface":
         tex = torch.rand(B, faces.shape[0], args.tex_size ** 2, 3, generator=g).to(device)
@@ -131,6 +147,159 @@ def build_inputs(args, device, seed):
         tex = torch.rand(B, faces.shape[0], 3, 8, generator=g).to(device)
         grad = (2 * torch.rand(B, 9, H, H, generator=g) - 1).to(device)
     return fv.contiguous(), tex, grad.contiguous()
+
+
+class RasterCase:
+    """One rasterizer configuration through the C ABI: inputs and buffers resident on the device,
+    `step()` = sv3d_raster_forward + sv3d_raster_backward, `kernel_times()` = average launch
+    duration of the two dominant kernels from HIP events on the launch stream."""
+
+    def __init__(self, device, batch, image_size, subdivide, mode, sigma, gamma=1e-4, tex_size=6,
+                 anti_aliasing=False, alpha_only=False, seed=1000):
+        from sv3d import _lib as L, workmodel
+        self.L, self.workmodel = L, workmodel
+        ns = argparse.Namespace(batch=batch, image_size=image_size, subdivide=subdivide, mode=mode,
+                                tex_size=tex_size, alpha_only=alpha_only)
+        self.fv, self.tex, self.grad = build_inputs(ns, device, seed)
+        self.mode, self.sigma = mode, sigma
+        B, F = self.fv.shape[0], self.fv.shape[1]
+        self.B, self.F = B, F
+        aa = 2 if anti_aliasing else 1
+        self.S = image_size * aa
+        m = {"none": L.SV3D_TEX_NONE, "surface": L.SV3D_TEX_SURFACE, "vertex": L.SV3D_TEX_VERTEX,
+             "vertex8": L.SV3D_TEX_VERTEX8}[mode]
+        self.p = L.make_params(B, F, self.S, aa, m, tex_size if mode == "surface" else 1, True, (0.0, 0.0, 0.0),
+                               1.0, 100.0, 1e-3, sigma, 1e-10, gamma, alpha_only=alpha_only and mode == "none")
+        rec_b, saved_b, ws_b = L.raster_sizes(self.p)
+        f32 = dict(dtype=torch.float32, device=device)
+        planes = 1 if self.p.alpha_only else (9 if mode == "vertex8" else 4)
+        self.rgba = torch.empty((B, planes, image_size, image_size), **f32)
+        assert self.grad.shape == self.rgba.shape, (self.grad.shape, self.rgba.shape)
+        self.rec = torch.empty(rec_b // 4, **f32)
+        self.saved = torch.empty(saved_b // 4, **f32)
+        self.gfv = torch.empty_like(self.fv)
+        self.gtex = torch.empty_like(self.tex) if self.tex is not None else None
+        vp = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+        self.stream = ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+        self.lib = L.lib()
+        pp = ctypes.byref(self.p)
+        # the buffers are the same on every step: their pointer arguments are built once
+        self.fwd_args = (pp, vp(self.fv), vp(self.tex), vp(self.rgba), vp(self.rec), vp(self.saved), self.stream)
+        self.bwd_args = (pp, vp(self.tex), vp(self.rec), vp(self.saved), vp(self.grad), vp(self.gfv), vp(self.gtex),
+                         None, ctypes.c_size_t(0), self.stream)
+
+    def step(self):
+        st = self.lib.sv3d_raster_forward(*self.fwd_args)
+        if st == 0:
+            st = self.lib.sv3d_raster_backward(*self.bwd_args)
+        if st != 0:
+            self.L.check(st, "sv3d_raster_forward / sv3d_raster_backward")
+
+    def kernel_times(self, ev, launches=60, per_batch=10):
+        """(forward ms, backward ms, launches per kernel): HIP events around batches of `per_batch`
+        back-to-back launches of the one kernel (sv3d_raster_*_timed_n), so that the events' own
+        stream time is spread over the batch."""
+        nb = max(1, launches // per_batch)
+        fe, be = ev.create(2 * nb), ev.create(2 * nb)
+        n = ctypes.c_int32(per_batch)
+        for j in range(nb):
+            self.L.check(self.lib.sv3d_raster_forward_timed_n(*self.fwd_args, fe[2 * j], fe[2 * j + 1], n), "fwd")
+        for j in range(nb):
+            self.L.check(self.lib.sv3d_raster_backward_timed_n(*self.bwd_args, be[2 * j], be[2 * j + 1], n), "bwd")
+        torch.cuda.synchronize()
+        fwd = sum(ev.elapsed_ms(fe[2 * j], fe[2 * j + 1]) for j in range(nb)) / (nb * per_batch)
+        bwd = sum(ev.elapsed_ms(be[2 * j], be[2 * j + 1]) for j in range(nb)) / (nb * per_batch)
+        ev.destroy(fe + be)
+        return fwd, bwd, nb * per_batch
+
+    def roofline(self, fwd_ms, bwd_ms, launches, traffic=None):
+        wm = self.workmodel
+        pairs = sum(wm.count_active_pairs(self.fv, self.S, self.sigma, 1e-10))
+        f_flop, b_flop = wm.raster_flops(pairs, colour=self.mode != "none")
+        if bwd_ms >= fwd_ms:
+            name, flop, ms = "raster_backward_kernel", b_flop, bwd_ms
+        else:
+            name, flop, ms = "raster_forward_kernel", f_flop, fwd_ms
+        achieved = flop / (ms * 1e-3) / 1e12
+        return {"bound": "valu", "kernel": name, "achieved": achieved, "peak": wm.FP32_VALU_PEAK_TFLOPS,
+                "unit": "TFLOP/s", "frac": achieved / wm.FP32_VALU_PEAK_TFLOPS, "traffic": traffic,
+                "avg_kernel_ms": ms, "kernel_time_samples": launches, "active_pairs_per_launch": pairs,
+                "flop_per_pair": flop / max(pairs, 1),
+                "other_kernel": {"fwd_ms": fwd_ms, "bwd_ms": bwd_ms,
+                                 "fwd_tflops": f_flop / (fwd_ms * 1e-3) / 1e12,
+                                 "bwd_tflops": b_flop / (bwd_ms * 1e-3) / 1e12,
+                                 "fwd_frac": f_flop / (fwd_ms * 1e-3) / 1e12 / wm.FP32_VALU_PEAK_TFLOPS,
+                                 "bwd_frac": b_flop / (bwd_ms * 1e-3) / 1e12 / wm.FP32_VALU_PEAK_TFLOPS}}
+
+
+def configs_leg(device, ev):
+    """The larger configurations, forward + backward through the C ABI on 64 images each (one GPU's
+    share of the reference recipe at batch 4: 8 camera hypotheses x (4 + 4 mirrored) images):
+    surface RGB on the 5120-face mesh, eight part maps in one pass, Chamfer 16 x 8192^2."""
+    from sv3d import _lib as L, workmodel
+    out = {}
+    for name, kw in (("hd_surface_rgb", dict(subdivide=4, mode="surface", tex_size=6)),
+                     ("part_maps_8_per_pass", dict(subdivide=3, mode="vertex8"))):
+        case = RasterCase(device, 64, 256, sigma=1e-5, gamma=1e-4, anti_aliasing=True, **kw)
+        for _ in range(5):
+            case.step()
+        torch.cuda.synchronize()
+        n = 20
+        t0 = time.perf_counter()
+        for _ in range(n):
+            case.step()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / n
+        fwd_ms, bwd_ms, launches = case.kernel_times(ev, launches=20, per_batch=5)
+        r = case.roofline(fwd_ms, bwd_ms, launches)
+        out[name] = {"workload": "%s fwd+bwd, 64 images, 256x256 (2x AA raster), %d faces, sigma=1e-5%s"
+                                 % ("surface-texture RGB (T=6)" if kw["mode"] == "surface" else
+                                    "eight per-vertex part maps in one pass", case.F,
+                                    "" if kw["mode"] == "surface" else " (x8 maps per image)"),
+                     "ms_per_step": 1e3 * dt, "images_per_s": 64 / dt, "fwd_kernel_ms": fwd_ms, "bwd_kernel_ms": bwd_ms,
+                     "dominant_kernel": r["kernel"], "frac": r["frac"], "tflops": r["achieved"],
+                     "active_pairs_per_launch": r["active_pairs_per_launch"], "flop_per_pair": r["flop_per_pair"]}
+        del case
+        torch.cuda.empty_cache()
+    # Chamfer 16 x 8192^2, forward + backward with both distance outputs carrying a gradient
+    lib = L.lib()
+    vp = lambda t: ctypes.c_void_p(t.data_ptr())
+    stream = ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+    B, N = 16, 8192
+    g = torch.Generator().manual_seed(5)
+    a, b = torch.randn(B, N, 3, generator=g).to(device), torch.randn(B, N, 3, generator=g).to(device)
+    d1, d2 = torch.empty(B, N, device=device), torch.empty(B, N, device=device)
+    i1 = torch.empty(B, N, dtype=torch.int32, device=device)
+    i2 = torch.empty(B, N, dtype=torch.int32, device=device)
+    gd1, gd2 = torch.rand(B, N, device=device), torch.rand(B, N, device=device)
+    ga, gb = torch.empty_like(a), torch.empty_like(b)
+
+    def fwd():
+        L.check(lib.sv3d_chamfer_forward(vp(a), vp(b), B, N, N, vp(d1), vp(d2), vp(i1), vp(i2), stream), "chamfer")
+
+    def bwd():
+        L.check(lib.sv3d_chamfer_backward(vp(a), vp(b), B, N, N, vp(gd1), vp(gd2), vp(i1), vp(i2), vp(ga), vp(gb),
+                                          stream), "chamfer backward")
+
+    def timed(fn, iters=20):
+        for _ in range(3):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / iters
+
+    f_ms, b_ms = timed(fwd), timed(bwd)
+    tf = workmodel.chamfer_flops(B, N, N) / (f_ms * 1e-3) / 1e12
+    out["chamfer_16x8192"] = {"workload": "Chamfer nearest neighbours, 16 cloud pairs of 8192 x 8192 points, forward + "
+                                          "backward (both distance outputs carry a gradient)",
+                              "forward_ms": f_ms, "backward_ms": b_ms, "cloud_pairs_per_s": B / ((f_ms + b_ms) * 1e-3),
+                              "dominant_kernel": "chamfer_nn_kernel", "tflops": tf,
+                              "frac": tf / workmodel.FP32_VALU_PEAK_TFLOPS}
+    return out
 
 
 def cpu_baseline(args, fv0, seconds):
@@ -316,44 +485,54 @@ def chamfer_leg(device):
     return rows
 
 
-def train_step_leg(args, device, world, rank):
-    """examples/cmr_synthetic.py's step (encoder, camera hypotheses, shared render passes, part maps,
-    Chamfer, regularisers, distance-map loss, autocast + clip + fused Adam x2) at batch 4 per rank."""
+def _timed_train(cmr, args, device, world, extra_flags, steps_wanted, dist_on):
+    """A trainer of examples/cmr_synthetic.py built from `extra_flags`, 6 warm-up steps, then
+    `steps_wanted` timed steps; returns (trainer, options, steps, seconds: max over ranks)."""
     import tempfile
-    if os.environ.get("SV3D_BENCH_FAIL_RANK") == str(rank):
-        raise RuntimeError("SV3D_BENCH_FAIL_RANK: this rank was asked to fail in the train_step leg")
-    cmr = _load_cmr_module()
     tmp = tempfile.mkdtemp(prefix="sv3d_bench_")
-    o = cmr.parse(["--batch_size", "4", "--seg_train", "1", "--print_scalars", "0", "--checkpoint_dir", tmp,
-                   "--name", "bench", "--dataset_size", "1024", "--save_latest_freq", "1000000"]
-                  + args.train_args.split())
+    o = cmr.parse(["--print_scalars", "0", "--checkpoint_dir", tmp, "--name", "bench", "--dataset_size", "1024",
+                   "--save_latest_freq", "1000000"] + extra_flags)
     o.epoch_fraction = 1.0
     from nnutils import train_utils
-    env = train_utils.init_distributed(gpu_id=device.index)
+    env = train_utils.init_distributed(gpu_id=device.index, force=dist_on)
     t = cmr.ShapeTrainer(o, env)
     t.init_training()
-    note("train_step: trainer built (%d parameters%s)"
-         % (sum(p.numel() for p in t.model.parameters()), ", DDP over %d ranks" % world if world > 1 else ""))
+    note("train_step %s: trainer built (%d parameters%s)"
+         % (" ".join(extra_flags), sum(p.numel() for p in t.model.parameters()),
+            ", DDP over %d rank(s), backend %s" % (world, env.backend) if dist_on else ""))
     o.num_iter = 6                                   # warm-up: library start-up, autotuning, allocator
     t.train()
     note("train_step: 6 warm-up steps done")
-    o.num_iter = args.train_steps
-    if world > 1:
+    o.num_iter = steps_wanted
+    if dist_on:
         torch.distributed.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     steps = t.train()
     torch.cuda.synchronize()
-    if world > 1:
+    if dist_on:
         torch.distributed.barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if dist_on:
         tt = torch.tensor([dt], dtype=torch.float64, device=device)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         dt = float(tt.item())
+    return t, o, steps, dt
+
+
+def train_step_leg(args, device, world, rank):
+    """examples/cmr_synthetic.py's step (encoder, camera hypotheses, shared render passes, part maps,
+    Chamfer, regularisers, distance-map loss, autocast + clip + fused Adam x2) at batch 4 per rank."""
+    if os.environ.get("SV3D_BENCH_FAIL_RANK") == str(rank):
+        raise RuntimeError("SV3D_BENCH_FAIL_RANK: this rank was asked to fail in the train_step leg")
+    cmr = _load_cmr_module()
+    dist_on = world > 1 or args.force_dist
+    t, o, steps, dt = _timed_train(cmr, args, device, world, ["--batch_size", "4", "--seg_train", "1"]
+                                   + args.train_args.split(), args.train_steps, dist_on)
     per_rank = steps * o.batch_size / dt
     graphed = None
-    if world == 1:
+    variants = None
+    if not dist_on:
         # the same step replayed from a HIP graph (one process only: the eager figure above is the
         # one that is comparable across rank counts).  Mode 1 holds forward + loss + backward, mode 2
         # the optimizer steps as well.
@@ -373,17 +552,35 @@ def train_step_leg(args, device, world, rank):
                    "what": "--cuda_graph 2: forward + loss + backward + unscale + clipping + the two fused Adam "
                            "steps + scaler update captured once in a HIP graph and replayed",
                    "forward_backward_only_ms_per_step": 1e3 * d1 / s1}
+    if world == 1 and not args.train_args:
+        del t
+        gc.collect()
+        torch.cuda.empty_cache()
+        variants = {}
+        for name, flags, what in (
+                ("hd_mesh", ["--batch_size", "4", "--seg_train", "1", "--subdivide", "4"],
+                 "the same step on the 2562-vertex / 5120-face mesh (subdivide 4, T = 6): 64 rendered images per pass"),
+                ("batch64_one_hypothesis", ["--batch_size", "64", "--seg_train", "0", "--num_hypo_cams", "1",
+                                            "--flip_pair", "0", "--num_parts", "0"],
+                 "64 dataset images per step, one camera hypothesis, no mirror pair: one RGB + silhouette pass over "
+                 "64 rendered images, no part maps")):
+            tv, ov, sv, dv = _timed_train(cmr, args, device, world, flags, max(4, args.train_steps // 2), dist_on)
+            variants[name] = {"what": what, "steps": sv, "ms_per_step": 1e3 * dv / sv,
+                              "dataset_images_per_s": sv * ov.batch_size / dv}
+            del tv
+            gc.collect()
+            torch.cuda.empty_cache()
     return {"what": "synthetic CMR-style training step (examples/cmr_synthetic.py): ResNet-18-shaped encoder under "
                     "autocast, 8 camera hypotheses x (4 + 4 mirrored) images = 64 rendered images per pass, RGB + "
                     "silhouette + 8 part maps from 2 shared passes, Chamfer, Laplacian + flatten, distance-map "
                     "loss, clip + fused Adam x2; LPIPS replaced by L1 (weights absent)",
             "batch_per_rank": o.batch_size, "rendered_images_per_pass": 16 * o.batch_size, "steps": steps,
             "ms_per_step": 1e3 * dt / steps, "dataset_images_per_s_per_rank": per_rank,
-            "dataset_images_per_s": per_rank * world, "ranks": world, "hip_graph": graphed,
+            "dataset_images_per_s": per_rank * world, "ranks": world, "hip_graph": graphed, "variants": variants,
             "gradient_all_reduce": ("%s via DistributedDataParallel over %d ranks"
                                     % ("RCCL" if torch.distributed.get_backend() == "nccl" else
                                        torch.distributed.get_backend(), torch.distributed.get_world_size()))
-            if world > 1 else "none (one rank)"}
+            if dist_on else "none (one rank)"}
 
 
 _T0 = time.perf_counter()
@@ -507,6 +704,7 @@ def pmc_traffic(args, kernel):
 
 def main():
     args = parse()
+    args.alpha_only = args.mode == "none"      # the silhouette caller keeps the alpha plane alone (softras.py:64)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     # diagnostic: every thread's Python stack on stderr if the run is still going after N seconds
     # (several ranks: armed by default at 0.8 of the extra legs' limit, counted from the start)
@@ -516,7 +714,9 @@ def main():
         faulthandler.dump_traceback_later(float(watchdog), repeat=False)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
         # SV3D_DIST_BACKEND=gloo+cuda rehearses the multi-rank run on one GPU (ranks share it,
         # collectives through gloo); the default is RCCL, one GPU per rank
@@ -524,72 +724,24 @@ def main():
         if rehearsal:
             local_rank %= max(torch.cuda.device_count(), 1)
         torch.cuda.set_device(local_rank)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
         if rehearsal:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
 
-    import sv3d
-    from sv3d import _lib as L, workmodel
+    import sv3d  # noqa: F401  (loads the libraries; fails loudly when they are missing)
 
-    fv, tex, grad = build_inputs(args, device, seed=1000 + rank)
-    B, F = fv.shape[0], fv.shape[1]
+    case = RasterCase(device, args.batch, args.image_size, args.subdivide, args.mode, args.sigma, args.gamma,
+                      args.tex_size, args.anti_aliasing, alpha_only=args.alpha_only, seed=1000 + rank)
+    B, F, S = case.B, case.F, case.S
     aa = 2 if args.anti_aliasing else 1
-    S = args.image_size * aa
-    mode = {"none": L.SV3D_TEX_NONE, "surface": L.SV3D_TEX_SURFACE, "vertex": L.SV3D_TEX_VERTEX}[args.mode]
-    p = L.make_params(B, F, S, aa, mode, args.tex_size if args.mode == "surface" else 1, True,
-                      (0.0, 0.0, 0.0), 1.0, 100.0, 1e-3, args.sigma, 1e-10, args.gamma)
-    rec_b, saved_b, ws_b = L.raster_sizes(p)
-    f32 = dict(dtype=torch.float32, device=device)
-    rgba = torch.empty((B, 4, args.image_size, args.image_size), **f32)
-    rec = torch.empty(rec_b // 4, **f32)
-    saved = torch.empty(saved_b // 4, **f32)
-    ws = torch.empty(ws_b // 4, **f32)
-    gfv = torch.empty_like(fv)
-    gtex = torch.empty_like(tex) if tex is not None else None
-    vp = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
-    stream = ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
-    lib = L.lib()
     ev = HipEvents()
     K, W = args.steps, args.warmup
-    # Kernel durations come from HIP events recorded on the kernels' stream inside the timed
-    # region.  An event pair costs a few microseconds of stream time, a fifth of this step, so
-    # only every `stride`-th step carries them; the other steps use the plain entry points.
-    # Such a step times ONE of the two kernels, forward and backward in turn, which halves that
-    # cost.  (Short runs: every 4th step, so that a 20-step run still rests on 3 + 2 samples.)
-    stride = max(1, args.event_stride) if K >= 100 else min(4, max(1, args.event_stride))
-    timed_steps = [i for i in range(K) if i % stride == 0]
-    if len(timed_steps) < 2 and K >= 2:
-        timed_steps = [0, K - 1]
-    n_fwd, n_bwd = (len(timed_steps) + 1) // 2, len(timed_steps) // 2
-    fe = ev.create(2 * max(n_fwd, 1))
-    be = ev.create(2 * max(n_bwd, 1))
-    slot = {i: j for j, i in enumerate(timed_steps)}
-    pp = ctypes.byref(p)
-
-    # the buffers are the same on every step: their pointer arguments are built once
-    a_fv, a_tex, a_rgba, a_rec, a_saved = vp(fv), vp(tex), vp(rgba), vp(rec), vp(saved)
-    a_grad, a_gfv, a_gtex, a_ws, a_wsb = vp(grad), vp(gfv), vp(gtex), vp(ws), ctypes.c_size_t(ws_b)
-
-    def step(i=None):
-        j = slot.get(i)
-        if j is None:
-            L.check(lib.sv3d_raster_forward(pp, a_fv, a_tex, a_rgba, a_rec, a_saved, stream), "fwd")
-            L.check(lib.sv3d_raster_backward(pp, a_tex, a_rec, a_saved, a_grad, a_gfv, a_gtex, a_ws, a_wsb,
-                                             stream), "bwd")
-        elif j % 2 == 0:                              # this step's forward kernel carries the events
-            L.check(lib.sv3d_raster_forward_timed(pp, a_fv, a_tex, a_rgba, a_rec, a_saved, stream,
-                                                  fe[j], fe[j + 1]), "fwd")
-            L.check(lib.sv3d_raster_backward(pp, a_tex, a_rec, a_saved, a_grad, a_gfv, a_gtex, a_ws, a_wsb,
-                                             stream), "bwd")
-        else:                                         # ... this one's backward kernel
-            L.check(lib.sv3d_raster_forward(pp, a_fv, a_tex, a_rgba, a_rec, a_saved, stream), "fwd")
-            L.check(lib.sv3d_raster_backward_timed(pp, a_tex, a_rec, a_saved, a_grad, a_gfv, a_gtex, a_ws,
-                                                   a_wsb, stream, be[j - 1], be[j]), "bwd")
+    step = case.step
 
     def barrier():
         if world > 1:
@@ -600,6 +752,7 @@ def main():
 
     def run_extras():                           # own warm-up and timing each
         for name, leg in (("api", lambda: api_leg(args, device, rank)), ("chamfer", lambda: chamfer_leg(device)),
+                          ("configs", lambda: configs_leg(device, ev)),
                           ("train_step", lambda: train_step_leg(args, device, world, rank))):
             extras["_leg"] = name
             note("leg %s starts" % name)
@@ -632,8 +785,8 @@ def main():
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for i in range(K):
-        step(i)
+    for _ in range(K):
+        step()
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
@@ -644,25 +797,13 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    fwd_ms = sum(ev.elapsed_ms(fe[2 * j], fe[2 * j + 1]) for j in range(n_fwd)) / n_fwd
-    # a one-step run has no backward sample: it reports the forward kernel
-    bwd_ms = sum(ev.elapsed_ms(be[2 * j], be[2 * j + 1]) for j in range(n_bwd)) / n_bwd if n_bwd else 0.0
-    pairs = sum(workmodel.count_active_pairs(fv, S, args.sigma, 1e-10))
-    f_flop, b_flop = workmodel.raster_flops(pairs, colour=args.mode != "none")
-    if bwd_ms >= fwd_ms:
-        name, flop, ms, n_ev = "raster_backward_kernel", b_flop, bwd_ms, n_bwd
-    else:
-        name, flop, ms, n_ev = "raster_forward_kernel", f_flop, fwd_ms, n_fwd
-    achieved = flop / (ms * 1e-3) / 1e12
-    roofline = {"bound": "valu", "kernel": name, "achieved": achieved,
-                "peak": workmodel.FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": achieved / workmodel.FP32_VALU_PEAK_TFLOPS,
-                "traffic": pmc_traffic(args, name),
-                "avg_kernel_ms": ms, "kernel_time_samples": n_ev, "active_pairs_per_launch": pairs,
-                "flop_per_pair": flop / max(pairs, 1),
-                "other_kernel": {"fwd_ms": fwd_ms, "bwd_ms": bwd_ms,
-                                 "fwd_tflops": f_flop / (fwd_ms * 1e-3) / 1e12,
-                                 "bwd_tflops": b_flop / (bwd_ms * 1e-3) / 1e12 if bwd_ms > 0 else None}}
+    # Kernel durations: a pass of its own, after the timed region (which carries no events), the GPU
+    # still warm from it.
+    for _ in range(16):
+        step()
+    fwd_ms, bwd_ms, launches = case.kernel_times(ev, launches=args.kernel_launches)
+    name = "raster_backward_kernel" if bwd_ms >= fwd_ms else "raster_forward_kernel"
+    roofline = case.roofline(fwd_ms, bwd_ms, launches, traffic=pmc_traffic(args, name))
 
     out = {
         "metric": "SoftRas fwd+bwd images/sec @256^2,1280 faces",
@@ -683,6 +824,8 @@ def main():
                                   {1: 42, 2: 162, 3: 642, 4: 2562}.get(args.subdivide, -1), F, args.sigma),
                    "batch_per_gpu": B, "image_size": args.image_size, "faces": F,
                    "parallelism": "image-sharded x%d" % world,
+                   "image_planes": "alpha only (the silhouette caller's view, nnutils/softras.py:64)"
+                   if case.p.alpha_only else "all",
                    "clock_preroll_ms": args.preroll_ms},
         "roofline": roofline,
     }
@@ -696,12 +839,12 @@ def main():
         return
     out.update({k: v for k, v in extras.items() if not k.startswith("_")})
     if world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(args, fv[0], args.cpu_seconds)
+        out["cpu_baseline"] = cpu_baseline(args, case.fv[0], args.cpu_seconds)
     print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
     main()
-    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
-        import torch.distributed as dist
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
         dist.destroy_process_group()

@@ -238,8 +238,11 @@ class ShapeTrainer(train_utils.Trainer):
     def forward(self, total_steps=0):
         o = self.opts
         Nc, Np = o.num_hypo_cams, o.num_parts
-        all_imgs = torch.cat([self.imgs, self.imgs.flip(-1)])               # main.py:310
-        masks_gt = torch.cat([self.masks, self.masks.flip(-1)])
+        if o.flip_pair:
+            all_imgs = torch.cat([self.imgs, self.imgs.flip(-1)])           # main.py:310
+            masks_gt = torch.cat([self.masks, self.masks.flip(-1)])
+        else:
+            all_imgs, masks_gt = self.imgs, self.masks
         B2 = all_imgs.shape[0]
         model = train_utils.unwrap(self.model)
         enc_in = all_imgs.contiguous(memory_format=torch.channels_last) if o.channels_last else all_imgs
@@ -282,10 +285,14 @@ class ShapeTrainer(train_utils.Trainer):
                 dts = dts.to(self.device)
             else:
                 dts = image_utils.compute_dt_barrier(self.masks)
-                dts = torch.cat([dts, dts.flip(-1)])
+                if o.flip_pair:
+                    dts = torch.cat([dts, dts.flip(-1)])
             loss = loss + o.dt_loss_wt * loss_utils.texture_dt_loss(flow, dts[:, None])
-        Bh = B2 // 2
-        loss = loss + o.chamf_loss_wt * loss_utils.chamfer_loss(pred_v[:Bh].detach(), pred_v[Bh:] * self.mirror)
+        if o.flip_pair:
+            Bh = B2 // 2
+            loss = loss + o.chamf_loss_wt * loss_utils.chamfer_loss(pred_v[:Bh].detach(), pred_v[Bh:] * self.mirror)
+        else:                                       # no mirrored half: every shape against its own mirror image
+            loss = loss + o.chamf_loss_wt * loss_utils.chamfer_loss(pred_v.detach(), pred_v * self.mirror)
         loss = loss + 5e-3 * self.triangle_loss_fn(pred_v).mean() + 5e-4 * self.flatten_loss_fn(pred_v).mean()
         self.total_loss = loss
 
@@ -312,6 +319,8 @@ def parse(argv=None):
     p.add_argument('--loader_thread', type=int, default=1,
                    help='with no worker processes: prepare batches on a background thread, three ahead')
     p.add_argument('--channels_last', type=int, default=0, help='encoder weights and activations in NHWC')
+    p.add_argument('--flip_pair', type=int, default=1,
+                   help='1: every image goes in with its mirror image, as main.py:310 does; 0: images alone')
     p.add_argument('--warmup_iter', type=int, default=0, help='untimed steps before the timed ones')
     p.add_argument('--dt_loss_wt', type=float, default=0.01, help='weight of the texture-flow distance-map loss')
     p.add_argument('--host_dt', type=int, default=0,
@@ -345,7 +354,7 @@ def main(argv=None):
         torch.cuda.synchronize()
     dt = time.time() - t0
     if t.env.is_main:
-        Bn = o.num_hypo_cams * 2 * o.batch_size
+        Bn = o.num_hypo_cams * (2 if o.flip_pair else 1) * o.batch_size
         parts = o.num_parts if o.seg_train else 0
         renders = 1 + (parts + 7) // 8 if o.share_renders else 2 + parts
         print('steps %d, %.1f ms/step, %.1f dataset images/s over %d rank(s) (%d rendered images x %d renders per step per rank)'

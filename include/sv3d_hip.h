@@ -11,10 +11,19 @@
  *     buffers owned by the caller and borrowed for the call.
  *   - `stream` is a hipStream_t passed as void*; every call only enqueues work
  *     on it (no allocation, no host synchronisation), so calls are graph-capture
- *     safe and re-entrant.  The current HIP device must own the buffers.
+ *     safe and re-entrant: the library keeps no mutable state between calls (the one
+ *     exception is named at sv3d_distance_transform_static).  The current HIP device
+ *     must own the buffers.
  *   - Return value: SV3D_OK or a negative sv3d_status; sv3d_strerror() names it.
- *   - Results are bitwise repeatable for fixed inputs: no float atomics to
- *     global memory anywhere.
+ *   - Results are bitwise repeatable for fixed inputs: no float atomics to global
+ *     memory anywhere, and every sum but one runs in an order the code fixes (register
+ *     trees, ordered LDS passes).  The exception: grad_textures of SV3D_TEX_SURFACE.
+ *     There one wave per face adds its lanes' texel gradients into wave-private LDS
+ *     tables with ds_add_f32; lanes of one instruction that hit the same address are
+ *     serialised by the LDS hardware, in an order the ISA does not spell out.  On
+ *     gfx950 that order is the same from run to run (tested: bit-equal repeats), so the
+ *     result is repeatable on this target; it is an observed property of the chip,
+ *     not a guarantee of the instruction set.
  */
 #ifndef SV3D_HIP_H
 #define SV3D_HIP_H
@@ -31,7 +40,8 @@ typedef enum sv3d_status {
     SV3D_ERR_INVALID_ARG = -1,   /* null pointer, non-positive size, bad enum */
     SV3D_ERR_UNSUPPORTED = -2,   /* size outside what the kernels are built for */
     SV3D_ERR_WORKSPACE = -3,     /* caller's buffer smaller than sv3d_raster_sizes() says */
-    SV3D_ERR_LAUNCH = -4         /* hipGetLastError() != hipSuccess after a launch */
+    SV3D_ERR_LAUNCH = -4,        /* hipGetLastError() != hipSuccess after a launch */
+    SV3D_ERR_NOT_READY = -5      /* a *_static call's first use on this GPU came under stream capture */
 } sv3d_status;
 
 /* SV3D_TEX_VERTEX8: eight scalar per-corner channels rendered in one pass (the reference renders
@@ -67,7 +77,15 @@ typedef struct sv3d_raster_params {
                            /*   `self.renderer(vs, fs)[:, -1]` does at nnutils/softras.py:64:        */
                            /*   rgba_out and grad_rgba are [B,1,S/aa,S/aa], the alpha plane; the     */
                            /*   three constant background planes are neither written nor read        */
+    int32_t backward_enumeration; /* SV3D_BWD_*: which pixels of a face's box the backward's waves   */
+                           /*   walk.  AUTO (0) lets the library pick per launch from raster size    */
+                           /*   and face count; BOXES / INTERVALS force one form (tests, tuning).    */
+                           /*   Both compute the same sums in a different order (equal to rounding). */
 } sv3d_raster_params;
+
+/* SV3D_BWD_BOXES: every pixel of the face's pixel box; SV3D_BWD_INTERVALS: per pixel row only the
+ * interval of columns that can hold an active pixel. */
+enum { SV3D_BWD_AUTO = 0, SV3D_BWD_BOXES = 1, SV3D_BWD_INTERVALS = 2 };
 
 const char *sv3d_strerror(int status);
 int sv3d_abi_version(void);
@@ -120,12 +138,19 @@ int sv3d_raster_backward_timed(const sv3d_raster_params *p, const float *texture
                                float *grad_textures, void *workspace, size_t workspace_bytes,
                                void *stream, void *ev_start, void *ev_stop);
 
-/* Tuning and test hook, no counterpart in the reference.  The backward's waves walk either every
- * pixel of a face's box or, per pixel row, only the interval of columns that can hold an active
- * pixel; the library picks per launch from raster size and face count.  mode 0 / 1 forces whole
- * boxes / row intervals for every later launch of the process, -1 gives the choice back.  Both
- * forms compute the same sums in a different order (results agree to rounding). */
-int sv3d_raster_backward_spans(int mode);
+/* The same with the dominant kernel launched `repeats` times (1..1000) back to back between the
+ * two events: an event pair costs microseconds of stream time, which a kernel of some tens of
+ * microseconds cannot carry alone; elapsed / repeats is its average launch duration.  Every launch
+ * writes the same values, so the outputs are those of the plain call. */
+int sv3d_raster_forward_timed_n(const sv3d_raster_params *p, const float *face_vertices,
+                                const float *textures, float *rgba_out, void *face_rec,
+                                void *pixel_saved, void *stream, void *ev_start, void *ev_stop,
+                                int32_t repeats);
+int sv3d_raster_backward_timed_n(const sv3d_raster_params *p, const float *textures,
+                                 const void *face_rec, const void *pixel_saved,
+                                 const float *grad_rgba, float *grad_face_vertices,
+                                 float *grad_textures, void *workspace, size_t workspace_bytes,
+                                 void *stream, void *ev_start, void *ev_stop, int32_t repeats);
 
 /* Replaces chamferdist's forward as called at nnutils/loss_utils.py:85-86
  * (`ChamferDistance()(xyz1, xyz2)`).
@@ -282,7 +307,10 @@ int sv3d_distance_transform(const float *masks, int32_t B, int32_t H, int32_t W,
  * workspace pair: the per-row distances live in an array of SV3D_DT_STATIC_MAX_PIXELS words
  * (16 MiB) inside the library's device image, one copy per GPU, held until the process ends.
  *   B*H*W > SV3D_DT_STATIC_MAX_PIXELS -> SV3D_ERR_WORKSPACE (nothing is launched).
- *   The call allocates and frees nothing.  Every call on one GPU uses that GPU's array: calls
+ *   The call allocates and frees nothing.  The first call on a GPU looks up the address of that
+ *   GPU's copy of the array (which may load the library's device code there): make it outside
+ *   stream capture -- any size will do; a first call on a capturing stream returns
+ *   SV3D_ERR_NOT_READY and enqueues nothing.  Every call on one GPU uses that GPU's array: calls
  *   whose execution can overlap on one GPU (different streams, no ordering between them) race;
  *   calls ordered on one stream, or on different GPUs, do not.                                 */
 #define SV3D_DT_STATIC_MAX_PIXELS (4 * 1024 * 1024)   /* e.g. 64 masks of 256 x 256 */

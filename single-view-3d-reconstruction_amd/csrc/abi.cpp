@@ -9,8 +9,9 @@ extern "C" const char *sv3d_strerror(int status)
     case SV3D_ERR_UNSUPPORTED: return "size outside the supported range";
     case SV3D_ERR_WORKSPACE: return "workspace too small for this call (or input beyond the built-in array of a *_static call)";
     case SV3D_ERR_LAUNCH: return "kernel launch failed (hipGetLastError)";
+    case SV3D_ERR_NOT_READY: return "first use of a *_static entry point on this GPU must happen outside stream capture";
     default: return "unknown sv3d status";
     }
 }
 
-extern "C" int sv3d_abi_version(void) { return 2; }
+extern "C" int sv3d_abi_version(void) { return 3; }

@@ -248,7 +248,9 @@ __global__ __launch_bounds__(kThreads) void chamfer_nn_small_kernel(
         dpp_lexmin<0x143, 0xc>(best, bi);           // row_bcast:31: rows 2 and 3 take in rows 0 and 1
         if (lane == 63 && q0 + k < nq) {
             dout[q0 + k] = best;
-            iout[q0 + k] = bi;
+            // no candidate compared below +inf (a NaN coordinate, or distances that overflow): index 0
+            // with distance +inf, as the tiled kernel reports it -- never an index outside the cloud
+            iout[q0 + k] = bi == 0x7fffffff ? 0 : bi;
         }
     }
 }

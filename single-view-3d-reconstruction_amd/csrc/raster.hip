@@ -26,8 +26,6 @@
 #include <stddef.h>
 #include <stdint.h>
 
-#include <atomic>
-
 #include "camera.h"
 #include "sv3d_hip.h"
 #include "tile_order.h"
@@ -1072,13 +1070,20 @@ __device__ inline float wave_sum_lane63(float v)
 // pixel row only the interval of columns that can hold an active pixel (below).  Finding a lane's
 // row then costs a short search per step, which pays once the faces are large enough in pixels
 // (the host decides from raster size and face count).
-// The backward kernel's arguments as a struct: the argument block of a kernel is laid out like one
-// (every argument at its natural alignment, in order), which gives the offset of the parameter
-// block that the kernel reads through the block's address.
+// The backward kernel's leading arguments, listed ONCE: the kernel's parameter list and the struct
+// that mirrors its argument block are both generated from this list, so they cannot part ways.
+// (The argument block of a kernel is laid out like a struct: every argument at its natural
+// alignment, in order.  The kernel reads its by-value parameter block through the block's address,
+// at the offset this struct gives.)
+#define SV3D_BWD_ARGS(X)                                                                             \
+    X(const float4 *__restrict__, rec) X(int, nf) X(int, order_batch) X(const float *__restrict__, saved) \
+    X(const float *__restrict__, grad_rgba) X(int, S_) X(int, aa_) X(int, alpha_only_) X(int, F_)     \
+    X(unsigned, inv_F_) X(float, inv_S_) X(const float *__restrict__, tex)                          \
+    X(const uint2 *__restrict__, pbox) X(float *__restrict__, gfv) X(float *__restrict__, gtex)
+#define SV3D_AS_FIELD(type, name) type name;
+#define SV3D_AS_PARAM(type, name) type name,
 struct BackwardArgsLayout {
-    const void *rec; int nf, order_batch; const void *saved, *grad_rgba;
-    int S, aa, alpha_only, F; unsigned inv_F; float inv_S;
-    const void *tex, *pbox; void *gfv, *gtex;
+    SV3D_BWD_ARGS(SV3D_AS_FIELD)
     DevParams P;
 };
 static_assert(offsetof(BackwardArgsLayout, tex) == 56, "the preloaded arguments are the first 14 dwords");
@@ -1090,10 +1095,7 @@ __global__ __launch_bounds__(kThreads) void raster_backward_kernel(
     // the wave: the record request goes out at once instead of after a first trip to memory for
     // the argument block.  nf = B * F; order_batch = B; S_ .. inv_S_ repeat fields of the
     // parameter block, which is requested together with the first pixels (below).
-    const float4 *__restrict__ rec, int nf, int order_batch, const float *__restrict__ saved,
-    const float *__restrict__ grad_rgba, int S_, int aa_, int alpha_only_, int F_, unsigned inv_F_, float inv_S_,
-    const float *__restrict__ tex, const uint2 *__restrict__ pbox, float *__restrict__ gfv,
-    float *__restrict__ gtex, DevParams P_block)
+    SV3D_BWD_ARGS(SV3D_AS_PARAM) DevParams P_block)
 {
     extern __shared__ float s_dyn[];            // SURFACE: per wave, texel gradient tables + texel values
 #ifdef SV3D_TRACE
@@ -1373,9 +1375,13 @@ __global__ __launch_bounds__(kThreads) void raster_backward_kernel(
     PixIn nxt;
     if (span_total > half * 64) nxt = fetch(half * 64);
     // The parameter block read through the argument block's address must be the one the preloaded
-    // arguments repeat.  It is, unless the kernel's argument list and BackwardArgsLayout part ways:
-    // then every wave of the launch leaves here, nothing is written, and the parity tests fail.
-    if (P.S != S_ || P.F != F_ || P.inv_F != inv_F_) return;
+    // arguments repeat.  Both are generated from one list (SV3D_BWD_ARGS), so it is; should a
+    // compiler ever lay the argument block out differently, no wave works on a block it cannot
+    // trust, and the face's gradient is written as NaN rather than left as stale memory.
+    if (P.S != S_ || P.F != F_ || P.inv_F != inv_F_) {
+        if (live && half == 0 && lane < 9) gfv[(size_t)gf * 9 + lane] = __int_as_float(0x7fc00000);
+        return;
+    }
 #ifdef SV3D_TRACE
     if (rg == 0) {
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     // the first pixels are here
@@ -1574,10 +1580,6 @@ __global__ __launch_bounds__(kThreads) void raster_backward_kernel(
 #define SV3D_BWD_HALVES_MAX_FACES 16384
 #endif
 constexpr long kBackwardHalvesMaxFaces = SV3D_BWD_HALVES_MAX_FACES;
-// -1: the library chooses the backward's pixel enumeration per launch; 0 / 1: whole boxes / row
-// intervals for every launch (tests and tuning, sv3d_raster_backward_spans)
-std::atomic<int> g_backward_spans{-1};
-
 int make_dev_params(const sv3d_raster_params *p, DevParams &d)
 {
     if (!p) return SV3D_ERR_INVALID_ARG;
@@ -1592,6 +1594,8 @@ int make_dev_params(const sv3d_raster_params *p, DevParams &d)
     if (p->texture_batch < 0 || (p->texture_batch > 0 && p->batch % p->texture_batch != 0))
         return SV3D_ERR_INVALID_ARG;
     if ((p->alpha_only != 0 && p->alpha_only != 1) || (p->alpha_only && p->texture_mode != SV3D_TEX_NONE))
+        return SV3D_ERR_INVALID_ARG;
+    if (p->backward_enumeration < SV3D_BWD_AUTO || p->backward_enumeration > SV3D_BWD_INTERVALS)
         return SV3D_ERR_INVALID_ARG;
     if (p->raster_size > 4096 || p->batch > 65535) return SV3D_ERR_UNSUPPORTED;
     if ((long)p->batch * p->num_faces > 0x7fffffffL / 4) return SV3D_ERR_UNSUPPORTED;
@@ -1681,7 +1685,8 @@ namespace {
 // mesh, face_vertices is an optional output.
 int raster_forward_impl(const sv3d_raster_params *p, const float *face_vertices, const float *textures,
                         float *rgba_out, void *face_rec, void *pixel_saved, void *stream,
-                        hipEvent_t ev_start, hipEvent_t ev_stop, const sv3d_mesh_input *mesh = nullptr)
+                        hipEvent_t ev_start, hipEvent_t ev_stop, const sv3d_mesh_input *mesh = nullptr,
+                        int repeats = 1)
 {
     DevParams d;
     const int st = make_dev_params(p, d);
@@ -1743,10 +1748,12 @@ int raster_forward_impl(const sv3d_raster_params *p, const float *face_vertices,
         else if (lo) SV3D_LAUNCH_FWD2(M, 1, true, false);                                              \
         else SV3D_LAUNCH_FWD2(M, 1, false, false);                                                     \
     } while (0)
+    for (int rep = 0; rep < repeats; ++rep) {       // > 1: measurement only, every launch writes the same values
     if (d.mode == SV3D_TEX_NONE) SV3D_LAUNCH_FWD(SV3D_TEX_NONE);
     else if (d.mode == SV3D_TEX_SURFACE) SV3D_LAUNCH_FWD(SV3D_TEX_SURFACE);
     else if (d.mode == SV3D_TEX_VERTEX) SV3D_LAUNCH_FWD(SV3D_TEX_VERTEX);
     else SV3D_LAUNCH_FWD(SV3D_TEX_VERTEX8);
+    }
 #undef SV3D_LAUNCH_FWD2
 #undef SV3D_LAUNCH_FWD
     if (ev_stop) (void)hipEventRecord(ev_stop, s);
@@ -1756,7 +1763,7 @@ int raster_forward_impl(const sv3d_raster_params *p, const float *face_vertices,
 int raster_backward_impl(const sv3d_raster_params *p, const float *textures, const void *face_rec,
                          const void *pixel_saved, const float *grad_rgba, float *grad_face_vertices,
                          float *grad_textures, void *workspace, size_t workspace_bytes, void *stream,
-                         hipEvent_t ev_start, hipEvent_t ev_stop)
+                         hipEvent_t ev_start, hipEvent_t ev_stop, int repeats = 1)
 {
     DevParams d;
     const int st = make_dev_params(p, d);
@@ -1778,8 +1785,8 @@ int raster_backward_impl(const sv3d_raster_params *p, const float *textures, con
     // Interval enumeration once a face covers enough pixels for it to pay: the expected box is a
     // few times S^2 / F pixels (measured with 1280 faces: 320^2 -8 %, 384^2 -6..12 %, 512^2
     // -13..28 %, but 256^2 +2..3 %; 5120 faces: 1024^2 -15 %, 512^2 +7 %; 320 faces at 256^2 -11 %)
-    const int forced = g_backward_spans.load(std::memory_order_relaxed);
-    const bool spans = forced < 0 ? (long)d.S * d.S >= 64L * d.F : forced != 0;
+    const bool spans = p->backward_enumeration == SV3D_BWD_AUTO ? (long)d.S * d.S >= 64L * d.F
+                                                                : p->backward_enumeration == SV3D_BWD_INTERVALS;
 #define SV3D_BWD_CASE(M, LO_, H_, SP_)                                                                  \
     hipLaunchKernelGGL((raster_backward_kernel<M, LO_, H_, SP_>), fgrid, block, lds, s, rec, d.B * d.F,  \
                        d.B, saved, grad_rgba, d.S, d.aa, d.alpha_only, d.F, d.inv_F, d.inv_S, textures, pbox,  \
@@ -1796,10 +1803,12 @@ int raster_backward_impl(const sv3d_raster_params *p, const float *textures, con
         if (spans) SV3D_BWD_SPANS(M, true);                                                             \
         else SV3D_BWD_SPANS(M, false);                                                                  \
     } while (0)
+    for (int rep = 0; rep < repeats; ++rep) {       // > 1: measurement only, every launch writes the same values
     if (d.mode == SV3D_TEX_NONE) SV3D_LAUNCH_BWD(SV3D_TEX_NONE);
     else if (d.mode == SV3D_TEX_SURFACE) SV3D_LAUNCH_BWD(SV3D_TEX_SURFACE);
     else if (d.mode == SV3D_TEX_VERTEX) SV3D_LAUNCH_BWD(SV3D_TEX_VERTEX);
     else SV3D_LAUNCH_BWD(SV3D_TEX_VERTEX8);
+    }
 #undef SV3D_LAUNCH_BWD
 #undef SV3D_BWD_SPANS
 #undef SV3D_BWD_CASE
@@ -1808,13 +1817,6 @@ int raster_backward_impl(const sv3d_raster_params *p, const float *textures, con
 }
 
 }  // namespace
-
-extern "C" int sv3d_raster_backward_spans(int mode)
-{
-    if (mode < -1 || mode > 1) return SV3D_ERR_INVALID_ARG;
-    g_backward_spans.store(mode, std::memory_order_relaxed);
-    return SV3D_OK;
-}
 
 extern "C" int sv3d_raster_forward(const sv3d_raster_params *p, const float *face_vertices,
                                    const float *textures, float *rgba_out, void *face_rec,
@@ -1861,4 +1863,27 @@ extern "C" int sv3d_raster_backward_timed(const sv3d_raster_params *p, const flo
     return raster_backward_impl(p, textures, face_rec, pixel_saved, grad_rgba, grad_face_vertices,
                                 grad_textures, workspace, workspace_bytes, stream,
                                 static_cast<hipEvent_t>(ev_start), static_cast<hipEvent_t>(ev_stop));
+}
+
+extern "C" int sv3d_raster_forward_timed_n(const sv3d_raster_params *p, const float *face_vertices,
+                                           const float *textures, float *rgba_out, void *face_rec,
+                                           void *pixel_saved, void *stream, void *ev_start, void *ev_stop,
+                                           int32_t repeats)
+{
+    if (repeats < 1 || repeats > 1000) return SV3D_ERR_INVALID_ARG;
+    return raster_forward_impl(p, face_vertices, textures, rgba_out, face_rec, pixel_saved, stream,
+                               static_cast<hipEvent_t>(ev_start), static_cast<hipEvent_t>(ev_stop), nullptr, repeats);
+}
+
+extern "C" int sv3d_raster_backward_timed_n(const sv3d_raster_params *p, const float *textures,
+                                            const void *face_rec, const void *pixel_saved,
+                                            const float *grad_rgba, float *grad_face_vertices,
+                                            float *grad_textures, void *workspace,
+                                            size_t workspace_bytes, void *stream, void *ev_start,
+                                            void *ev_stop, int32_t repeats)
+{
+    if (repeats < 1 || repeats > 1000) return SV3D_ERR_INVALID_ARG;
+    return raster_backward_impl(p, textures, face_rec, pixel_saved, grad_rgba, grad_face_vertices,
+                                grad_textures, workspace, workspace_bytes, stream,
+                                static_cast<hipEvent_t>(ev_start), static_cast<hipEvent_t>(ev_stop), repeats);
 }

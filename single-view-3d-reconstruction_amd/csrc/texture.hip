@@ -329,13 +329,25 @@ constexpr int kMaxDevices = 64;
 uint32_t *g_scratch_ptr[kMaxDevices];            // device address of `scratch` on each GPU, once looked up
 std::mutex g_scratch_mutex;
 
-// Address of the current device's copy of `scratch`, or nullptr.
-uint32_t *scratch_on_current_device()
+// Address of the current device's copy of `scratch`, or nullptr with `status` saying why.  The
+// first call on a device looks the address up, which may load the library's code object on that
+// device: not something to do while `stream` is capturing, so such a call is refused instead.
+uint32_t *scratch_on_current_device(hipStream_t stream, int &status)
 {
     int dev = -1;
+    status = SV3D_ERR_LAUNCH;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return nullptr;
     std::lock_guard<std::mutex> lock(g_scratch_mutex);
     if (!g_scratch_ptr[dev]) {
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(stream, &cap) != hipSuccess) {
+            (void)hipGetLastError();
+            return nullptr;
+        }
+        if (cap != hipStreamCaptureStatusNone) {
+            status = SV3D_ERR_NOT_READY;
+            return nullptr;
+        }
         void *p = nullptr;
         if (hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)) != hipSuccess || !p) {
             (void)hipGetLastError();
@@ -365,8 +377,9 @@ extern "C" int sv3d_distance_transform_static(const float *masks, int32_t B, int
     if (!masks || !out || B <= 0 || H <= 0 || W <= 0) return SV3D_ERR_INVALID_ARG;
     if (W > kDtMaxSize || H > kDtMaxSize || B > 65535) return SV3D_ERR_UNSUPPORTED;
     if ((size_t)B * H * W > (size_t)SV3D_DT_STATIC_MAX_PIXELS) return SV3D_ERR_WORKSPACE;
-    uint32_t *pairs = scratch_on_current_device();
-    if (!pairs) return SV3D_ERR_LAUNCH;
+    int why = SV3D_OK;
+    uint32_t *pairs = scratch_on_current_device((hipStream_t)stream, why);
+    if (!pairs) return why;
     // every word the column pass reads was written by the row pass of this same call: nothing to clear
     return distance_transform_launch(masks, B, H, W, barrier, k, out, pairs, (hipStream_t)stream);
 }

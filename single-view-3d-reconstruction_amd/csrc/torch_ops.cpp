@@ -28,6 +28,7 @@
 
 #include <string>
 #include <tuple>
+#include <utility>
 #include <vector>
 
 #include "sv3d_hip.h"
@@ -74,12 +75,19 @@ void same_device(const Tensor &ref, const Tensor &t, const char *name)
     TORCH_CHECK(t.device() == ref.device(), name, " is on ", t.device(), ", expected ", ref.device());
 }
 
-// icfg: raster_size, aa, texture_mode, texture_res, double_side, alpha_only
+// icfg: raster_size, aa, texture_mode, texture_res, double_side, alpha_only[, backward_enumeration]
 // fcfg: background r g b, near, far, eps, sigma, dist_eps, gamma
+void check_icfg(IntList icfg)
+{
+    TORCH_CHECK_VALUE(icfg.size() == 6 || icfg.size() == 7, "raster configuration must hold 6 or 7 integers");
+}
+
 sv3d_raster_params make_params(int64_t B, int64_t F, IntList icfg, FloatList fcfg, const optional<Tensor> &tex)
 {
-    TORCH_CHECK_VALUE(icfg.size() == 6 && fcfg.size() == 9, "raster configuration must hold 6 integers and 9 floats");
+    check_icfg(icfg);
+    TORCH_CHECK_VALUE(fcfg.size() == 9, "raster configuration must hold 9 floats");
     sv3d_raster_params p;
+    p.backward_enumeration = icfg.size() > 6 ? (int32_t)icfg[6] : SV3D_BWD_AUTO;
     p.batch = (int32_t)B;
     p.num_faces = (int32_t)F;
     p.raster_size = (int32_t)icfg[0];
@@ -165,6 +173,24 @@ RasterBuffers alloc_raster(const sv3d_raster_params &p, const at::TensorOptions 
     return b;
 }
 
+// The two buffers a forward call hands to its backward, as the backward operators receive them from
+// a caller: they must be what sv3d_raster_sizes says for this configuration, or the kernels would
+// read past their ends.
+void check_saved_buffers(const sv3d_raster_params &p, const Tensor &ref, const Tensor &face_rec, const Tensor &pixel_saved)
+{
+    size_t rec_b = 0, saved_b = 0, ws_b = 0;
+    check_status(sv3d_raster_sizes(&p, &rec_b, &saved_b, &ws_b), "sv3d_raster_sizes");
+    for (const auto &pr : {std::make_pair(&face_rec, rec_b), std::make_pair(&pixel_saved, saved_b)}) {
+        const Tensor &t = *pr.first;
+        const char *name = pr.first == &face_rec ? "face_rec" : "pixel_saved";
+        TORCH_CHECK_VALUE(t.defined() && t.scalar_type() == at::kFloat && t.is_contiguous(), name,
+                          " must be a contiguous float32 tensor (an output of the forward operator)");
+        same_device(ref, t, name);
+        TORCH_CHECK_VALUE((size_t)t.numel() * 4 >= pr.second, name, " holds ", t.numel() * 4, " bytes, this configuration needs ",
+                          pr.second);
+    }
+}
+
 Tensor fold_grad_textures(const Tensor &gtex, const Tensor &tex)
 {
     // per-image gradients summed over the images that shared a texture set
@@ -182,7 +208,7 @@ std::tuple<Tensor, Tensor, Tensor> soft_rasterize_gpu(const Tensor &face_vertice
                           face_vertices.size(0) > 0 && face_vertices.size(1) > 0,
                       "face_vertices must be [B,F,3,3], got ", face_vertices.sizes());
     const int64_t B = face_vertices.size(0), F = face_vertices.size(1);
-    TORCH_CHECK_VALUE(icfg.size() == 6, "raster configuration must hold 6 integers");
+    check_icfg(icfg);
     check_textures(textures, B, F, icfg[2], icfg[3]);
     const Tensor fv = f32c(face_vertices);
     Tensor tex;
@@ -222,14 +248,20 @@ std::tuple<Tensor, Tensor> soft_rasterize_backward_gpu(const Tensor &grad_rgba, 
                                                        const Tensor &face_rec, const Tensor &pixel_saved,
                                                        IntList shape, IntList icfg, FloatList fcfg, bool need_textures)
 {
-    TORCH_CHECK_VALUE(shape.size() == 2 && icfg.size() == 6, "shape must be (batch, faces)");
+    check_icfg(icfg);
+    TORCH_CHECK_VALUE(shape.size() == 2 && shape[0] > 0 && shape[1] > 0, "shape must be (batch, faces)");
     const int64_t B = shape[0], F = shape[1];
     const Tensor g = f32c(grad_rgba);
     Tensor tex;
-    if (icfg[2] != SV3D_TEX_NONE) tex = f32c(*textures);
+    if (icfg[2] != SV3D_TEX_NONE) {
+        check_textures(textures, B, F, icfg[2], icfg[3]);
+        same_device(g, *textures, "textures");
+        tex = f32c(*textures);
+    }
     const sv3d_raster_params p = make_params(B, F, icfg, fcfg, textures);
     TORCH_CHECK_VALUE(g.numel() == B * image_planes(p) * (p.raster_size / p.aa) * (p.raster_size / p.aa),
                       "grad_rgba does not match the rendered image, got ", g.sizes());
+    check_saved_buffers(p, g, face_rec, pixel_saved);
     Launch L(g);
     Tensor gfv = at::empty({B, F, 3, 3}, g.options());
     Tensor gtex = at::empty({0}, g.options());
@@ -264,7 +296,7 @@ std::tuple<Tensor, Tensor, Tensor> render_gpu(const Tensor &vertices, const Tens
 {
     check_mesh(vertices, cams, faces);
     const int64_t B = vertices.size(0), F = faces.size(1);
-    TORCH_CHECK_VALUE(icfg.size() == 6, "raster configuration must hold 6 integers");
+    check_icfg(icfg);
     check_textures(textures, B, F, icfg[2], icfg[3]);
     const Tensor v = f32c(vertices), c = f32c(cams), f = faces.contiguous();
     Tensor tex;
@@ -295,14 +327,21 @@ std::tuple<Tensor, Tensor, Tensor> render_backward_gpu(const Tensor &grad_rgba, 
                                                        const Tensor &pixel_saved, FloatList mesh_cfg, IntList icfg,
                                                        FloatList fcfg, bool need_textures)
 {
+    check_mesh(vertices, cams, faces);
+    same_device(grad_rgba, vertices, "vertices");
     const Tensor g = f32c(grad_rgba), v = f32c(vertices), c = f32c(cams), f = faces.contiguous();
     const int64_t B = v.size(0), F = f.size(1);
-    TORCH_CHECK_VALUE(icfg.size() == 6, "raster configuration must hold 6 integers");
+    check_icfg(icfg);
     Tensor tex;
-    if (icfg[2] != SV3D_TEX_NONE) tex = f32c(*textures);
+    if (icfg[2] != SV3D_TEX_NONE) {
+        check_textures(textures, B, F, icfg[2], icfg[3]);
+        same_device(g, *textures, "textures");
+        tex = f32c(*textures);
+    }
     const sv3d_raster_params p = make_params(B, F, icfg, fcfg, textures);
     TORCH_CHECK_VALUE(g.numel() == B * image_planes(p) * (p.raster_size / p.aa) * (p.raster_size / p.aa),
                       "grad_rgba does not match the rendered image, got ", g.sizes());
+    check_saved_buffers(p, g, face_rec, pixel_saved);
     Launch L(g);
     Tensor gfv = at::empty({B, F, 3, 3}, g.options());
     Tensor gtex = at::empty({0}, g.options());
@@ -374,11 +413,24 @@ std::tuple<Tensor, Tensor> chamfer_nn_backward_gpu(const Tensor &xyz1, const Ten
                                                    const optional<Tensor> &grad_dist2, const Tensor &idx1,
                                                    const Tensor &idx2, bool need1, bool need2)
 {
+    check_clouds(xyz1, xyz2);
+    same_device(xyz1, xyz2, "xyz2");
     const Tensor a = f32c(xyz1), b = f32c(xyz2);
     const int64_t B = a.size(0), N = a.size(1), M = b.size(1);
     Tensor gd1, gd2;
     if (grad_dist1.has_value() && grad_dist1->defined()) gd1 = f32c(*grad_dist1);
     if (grad_dist2.has_value() && grad_dist2->defined()) gd2 = f32c(*grad_dist2);
+    TORCH_CHECK_VALUE(!gd1.defined() || gd1.numel() == B * N, "grad_dist1 must be [B,N], got ", gd1.sizes());
+    TORCH_CHECK_VALUE(!gd2.defined() || gd2.numel() == B * M, "grad_dist2 must be [B,M], got ", gd2.sizes());
+    if (gd1.defined()) same_device(a, gd1, "grad_dist1");
+    if (gd2.defined()) same_device(a, gd2, "grad_dist2");
+    for (const auto &pr : {std::make_pair(&idx1, B * N), std::make_pair(&idx2, B * M)}) {
+        const Tensor &t = *pr.first;
+        const char *name = pr.first == &idx1 ? "idx1" : "idx2";
+        TORCH_CHECK_VALUE(t.defined() && t.scalar_type() == at::kInt && t.is_contiguous() && t.numel() == pr.second, name,
+                          " must be a contiguous int32 tensor with one entry per point");
+        same_device(a, t, name);
+    }
     Launch L(a);
     Tensor g1 = need1 ? at::empty_like(a) : at::empty({0}, a.options());
     Tensor g2 = need2 ? at::empty_like(b) : at::empty({0}, a.options());

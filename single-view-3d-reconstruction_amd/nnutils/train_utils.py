@@ -30,7 +30,10 @@ from then on replays it; unscale, clipping, the optimizer steps and the scaler u
 needs `--fused_adam 1`, whose step takes the scaler's inf check as a device tensor (the unfused
 optimizers make GradScaler read that check on the host, which a capture cannot hold).  Everything
 in the captured part must be free of host synchronisation and of shapes that change from step to
-step.
+step.  A captured step also freezes every Python-side decision `forward` took while it was
+captured: a subclass whose `forward` branches on the step number (the reference's does --
+main.py:299-308: pose / shape warm-up, alternating vertex updates) names what it branches on in
+`graph_key(total_steps)`, and the trainer keeps one captured graph per key.
 
 `--fused_adam 1` (default on a GPU): the reference's `torch.optim.Adam(lr, betas=(beta1, 0.999))`
 (:165-172) with `fused=True` -- the same update rule in one multi-tensor kernel per optimizer
@@ -85,10 +88,11 @@ def add_training_flags(parser=None):
 class DistEnv(object):
     """Rank bookkeeping of one process."""
 
-    def __init__(self, rank=0, local_rank=0, world_size=1, device=None, backend=None):
+    def __init__(self, rank=0, local_rank=0, world_size=1, device=None, backend=None, group_of_one=False):
         self.rank, self.local_rank, self.world_size = rank, local_rank, world_size
         self.device = device if device is not None else torch.device('cpu')
         self.backend = backend
+        self.group_of_one = group_of_one        # a process group was opened although there is one rank
 
     @property
     def is_main(self):
@@ -96,12 +100,14 @@ class DistEnv(object):
 
     @property
     def distributed(self):
-        return self.world_size > 1
+        return self.world_size > 1 or self.group_of_one
 
 
-def init_distributed(backend=None, gpu_id=0):
+def init_distributed(backend=None, gpu_id=0, force=False):
     """Open the process group described by the environment (no-op for a single process).
-    Must run before the model is built: it selects this rank's GPU."""
+    Must run before the model is built: it selects this rank's GPU.  `force` (or SV3D_FORCE_DIST=1)
+    opens the group for a single process as well, so that communicator creation, the DDP wrappers
+    and their gradient all-reduce run exactly as they do with several ranks."""
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', str(gpu_id)))
@@ -119,12 +125,18 @@ def init_distributed(backend=None, gpu_id=0):
         device = torch.device('cuda', local_rank)
     else:
         device = torch.device('cpu')
-    if world > 1 and not dist.is_initialized():
+    force = bool(force) or os.environ.get('SV3D_FORCE_DIST') == '1'
+    grouped = world > 1 or force
+    if grouped:
         backend = backend or ('nccl' if use_cuda else 'gloo')
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        kwargs = {'device_id': device} if backend == 'nccl' else {}
-        dist.init_process_group(backend, rank=rank, world_size=world, **kwargs)
-    return DistEnv(rank, local_rank, world, device, backend if world > 1 else None)
+        if not dist.is_initialized():
+            os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+            os.environ.setdefault('MASTER_PORT', '29500')
+            kwargs = {'device_id': device} if backend == 'nccl' else {}
+            dist.init_process_group(backend, rank=rank, world_size=world, **kwargs)
+        else:
+            backend = dist.get_backend()
+    return DistEnv(rank, local_rank, world, device, backend if grouped else None, group_of_one=grouped and world == 1)
 
 
 def unwrap(module):
@@ -138,7 +150,9 @@ class Trainer(object):
 
     def __init__(self, opts, env=None):
         self.opts = opts
-        self._graph = None              # captured step: {'graph', 'static'}
+        self._graph = None              # the captured step in use: {'graph', 'static', 'loss', 'whole', 'key'}
+        self._graphs = {}               # (whole, graph_key) -> captured step
+        self._graph_static = None       # static copies of the step's inputs, shared by the captured steps
         self._graph_eager_steps = 0
         self.env = env if env is not None else init_distributed(gpu_id=getattr(opts, 'gpu_id', 0))
         self.device = self.env.device
@@ -296,6 +310,22 @@ class Trainer(object):
     def _graph_whole_step(self):
         return int(getattr(self.opts, 'cuda_graph', 0)) >= 2
 
+    def graph_key(self, total_steps):
+        """What `forward`'s Python-side control flow depends on at this step, as a hashable value
+        (for the reference's schedule: `(iters < warmup_pose_iter, iters < warmup_shape_iter,
+        iters % (2 * warmup_shape_iter) >= warmup_shape_iter)`).  A replayed graph repeats the
+        branch it was captured on, so `--cuda_graph` keeps one captured step per key and captures
+        again the first time a new key comes up.  The default, None, says that `forward` does not
+        look at the step number."""
+        return None
+
+    def _norm_state(self):
+        """The running statistics of every normalisation layer (what a forward pass in training
+        mode changes besides the gradients)."""
+        mods = [self.model] + ([self.part_basis_generator] if self._second_optimizer() else [])
+        return [b for m in mods for mod in m.modules() if isinstance(mod, torch.nn.modules.batchnorm._NormBase)
+                for b in mod.buffers(recurse=False)]
+
     def _make_optimizers_capturable(self):
         """A captured optimizer step must keep its step counts on the device and take the inf check
         as a tensor: Adam with fused=True does both once its groups are marked capturable."""
@@ -311,24 +341,40 @@ class Trainer(object):
         """Forward + loss + backward of this step (and, with `--cuda_graph 2`, the optimizer steps)
         from the captured graph (captured here on first use)."""
         whole = self._graph_whole_step()
-        if self._graph is not None and self._graph['whole'] != whole:
-            self._graph = None          # the mode changed between two train() calls: capture again
+        key = (whole, self.graph_key(total_steps))
+        self._graph = self._graphs.get(key)       # the mode or the schedule's branch may have changed
+        if self._graph_static is None:
+            self._graph_static = {name: torch.empty_like(getattr(self, name)) for name in self.graph_inputs}
+        static = self._graph_static
+        for name, buf in static.items():
+            src = getattr(self, name)
+            if src.shape != buf.shape or src.dtype != buf.dtype:
+                raise RuntimeError('--cuda_graph needs a constant batch: %s is %s, the captured step has %s'
+                                   % (name, tuple(src.shape), tuple(buf.shape)))
+            buf.copy_(src, non_blocking=True)
+            setattr(self, name, buf)
         if self._graph is None:
             if whole:
                 self._make_optimizers_capturable()
-            static = {name: torch.empty_like(getattr(self, name)) for name in self.graph_inputs}
-            for name, buf in static.items():
-                buf.copy_(getattr(self, name))
-                setattr(self, name, buf)
             # torch's recipe: a few uncaptured passes on a side stream, then the capture; the gradients
-            # of these passes are dropped, the weights do not move.  The last eager step's loss still
-            # holds its autograd graph, whose gradient-accumulation nodes belong to the default stream.
+            # of these passes are dropped, the weights do not move, and the normalisation layers'
+            # running statistics are put back afterwards (the passes would otherwise count this batch
+            # twice more).  The last eager step's loss still holds its autograd graph, whose
+            # gradient-accumulation nodes belong to the default stream.
             self.total_loss = None
             # (the parameters' accumulation nodes were made on the default stream by the eager steps;
             # torch warns about that once per pass on the side stream, and syncs as needed)
             quiet = getattr(torch.autograd.graph, 'set_warn_on_accumulate_grad_stream_mismatch', None)
             if quiet is not None:
                 quiet(False)
+            norm = self._norm_state()
+            kept = [b.detach().clone() for b in norm]
+            # A later capture (another graph_key) must leave the gradients where the first captured
+            # step put them: the other graphs write those tensors, and the optimizers read them.
+            params = [p for g in self.optimizer.param_groups for p in g['params']]
+            if self._second_optimizer():
+                params += [p for g in self.optimizer_2.param_groups for p in g['params']]
+            held = [p.grad for p in params] if self._graphs else None
             side = torch.cuda.Stream(self.device)
             side.wait_stream(torch.cuda.current_stream(self.device))
             with torch.cuda.stream(side):
@@ -336,21 +382,28 @@ class Trainer(object):
                     self._zero_grads()
                     self._forward_backward(total_steps, scaler)
             torch.cuda.current_stream(self.device).wait_stream(side)
+            # nothing made by those passes may be released inside the capture (a tensor with autograd
+            # history that was allocated on the side stream and dies during capture ends the capture
+            # in a segmentation fault on this PyTorch-ROCm build): their loss goes now
+            self.total_loss = None
+            with torch.no_grad():
+                for b, k in zip(norm, kept):
+                    b.copy_(k)
             self._zero_grads()
+            if held is not None:
+                for p, g in zip(params, held):
+                    p.grad = g
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
+                if held is not None:                # zero in place, as part of the replayed step
+                    self.optimizer.zero_grad(set_to_none=False)
+                    if self._second_optimizer():
+                        self.optimizer_2.zero_grad(set_to_none=False)
                 self._forward_backward(total_steps, scaler)
                 if whole:
                     self._optimizer_steps(scaler)
-            self._graph = {'graph': graph, 'static': static, 'loss': self.total_loss, 'whole': whole}
-        else:
-            for name, buf in self._graph['static'].items():
-                src = getattr(self, name)
-                if src.shape != buf.shape or src.dtype != buf.dtype:
-                    raise RuntimeError('--cuda_graph needs a constant batch: %s is %s, the captured step has %s'
-                                       % (name, tuple(src.shape), tuple(buf.shape)))
-                buf.copy_(src, non_blocking=True)
-                setattr(self, name, buf)
+            self._graph = {'graph': graph, 'static': static, 'loss': self.total_loss, 'whole': whole, 'key': key}
+            self._graphs[key] = self._graph
         self._graph['graph'].replay()
         self.total_loss = self._graph['loss']
 

@@ -11,10 +11,12 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsv3d_hip.so")
 
 SV3D_TEX_NONE, SV3D_TEX_SURFACE, SV3D_TEX_VERTEX, SV3D_TEX_VERTEX8 = 0, 1, 2, 3
+SV3D_BWD_AUTO, SV3D_BWD_BOXES, SV3D_BWD_INTERVALS = 0, 1, 2
 
 EXPORTS = (
     "sv3d_strerror", "sv3d_abi_version", "sv3d_raster_sizes", "sv3d_raster_forward",
-    "sv3d_raster_backward", "sv3d_raster_forward_timed", "sv3d_raster_backward_timed", "sv3d_raster_backward_spans",
+    "sv3d_raster_backward", "sv3d_raster_forward_timed", "sv3d_raster_backward_timed",
+    "sv3d_raster_forward_timed_n", "sv3d_raster_backward_timed_n",
     "sv3d_chamfer_forward", "sv3d_chamfer_backward",
     "sv3d_face_gather", "sv3d_face_scatter",
     "sv3d_project_gather", "sv3d_project_scatter", "sv3d_render_forward",
@@ -35,7 +37,7 @@ class RasterParams(ctypes.Structure):
         ("background", ctypes.c_float * 3),
         ("near_plane", ctypes.c_float), ("far_plane", ctypes.c_float), ("eps", ctypes.c_float),
         ("sigma", ctypes.c_float), ("dist_eps", ctypes.c_float), ("gamma", ctypes.c_float),
-        ("alpha_only", ctypes.c_int32),
+        ("alpha_only", ctypes.c_int32), ("backward_enumeration", ctypes.c_int32),
     ]
 
 
@@ -76,7 +78,8 @@ def lib():
         L.sv3d_raster_backward.argtypes = [pp, vp, vp, vp, vp, vp, vp, vp, sz, vp]
         L.sv3d_raster_forward_timed.argtypes = [pp, vp, vp, vp, vp, vp, vp, vp, vp]
         L.sv3d_raster_backward_timed.argtypes = [pp, vp, vp, vp, vp, vp, vp, vp, sz, vp, vp, vp]
-        L.sv3d_raster_backward_spans.argtypes = [ctypes.c_int]
+        L.sv3d_raster_forward_timed_n.argtypes = [pp, vp, vp, vp, vp, vp, vp, vp, vp, i32]
+        L.sv3d_raster_backward_timed_n.argtypes = [pp, vp, vp, vp, vp, vp, vp, vp, sz, vp, vp, vp, i32]
         L.sv3d_chamfer_forward.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp, vp, vp]
         L.sv3d_chamfer_backward.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp]
         f3 = ctypes.POINTER(ctypes.c_float)
@@ -109,7 +112,8 @@ def check(status, what):
 
 
 def make_params(batch, num_faces, raster_size, aa, texture_mode, texture_res, double_side,
-                background, near, far, eps, sigma, dist_eps, gamma, alpha_only=False):
+                background, near, far, eps, sigma, dist_eps, gamma, alpha_only=False,
+                backward_enumeration=SV3D_BWD_AUTO):
     p = RasterParams()
     p.batch, p.num_faces, p.raster_size, p.aa = int(batch), int(num_faces), int(raster_size), int(aa)
     p.texture_mode, p.texture_res = int(texture_mode), int(texture_res)
@@ -118,6 +122,7 @@ def make_params(batch, num_faces, raster_size, aa, texture_mode, texture_res, do
     p.near_plane, p.far_plane, p.eps = float(near), float(far), float(eps)
     p.sigma, p.dist_eps, p.gamma = float(sigma), float(dist_eps), float(gamma)
     p.alpha_only = int(bool(alpha_only))
+    p.backward_enumeration = int(backward_enumeration)
     return p
 
 

@@ -60,13 +60,28 @@ def _texture_mode(textures, texture_type):
     return mode, res
 
 
+# `sv3d_raster_params.backward_enumeration` of the calls made through this module: the library's
+# own choice unless a test or a tuning run asks for one form (the C ABI itself keeps no such state)
+_backward_enumeration = L.SV3D_BWD_AUTO
+
+
+def set_backward_enumeration(mode):
+    """"auto" (the library picks per launch), "boxes" or "intervals" for the rasterizer backward of
+    every later call through this module; returns the previous setting."""
+    global _backward_enumeration
+    names = {"auto": L.SV3D_BWD_AUTO, "boxes": L.SV3D_BWD_BOXES, "intervals": L.SV3D_BWD_INTERVALS}
+    prev = [k for k, v in names.items() if v == _backward_enumeration][0]
+    _backward_enumeration = names[mode]
+    return prev
+
+
 def raster_config(image_size, anti_aliasing, mode, res, fill_back, alpha_only, background_color, near, far,
                   eps, sigma_val, dist_eps, gamma_val):
     """(icfg, fcfg): the integer and float halves of `sv3d_raster_params` as the operators take them
-    (raster_size, aa, texture_mode, texture_res, double_side, alpha_only; background r g b, near,
-    far, eps, sigma, dist_eps, gamma)."""
+    (raster_size, aa, texture_mode, texture_res, double_side, alpha_only, backward_enumeration;
+    background r g b, near, far, eps, sigma, dist_eps, gamma)."""
     aa = 2 if anti_aliasing else 1
-    return ([int(image_size) * aa, aa, mode, res, int(bool(fill_back)), int(bool(alpha_only))],
+    return ([int(image_size) * aa, aa, mode, res, int(bool(fill_back)), int(bool(alpha_only)), _backward_enumeration],
             [float(background_color[0]), float(background_color[1]), float(background_color[2]), float(near),
              float(far), float(eps), float(sigma_val), float(dist_eps), float(gamma_val)])
 

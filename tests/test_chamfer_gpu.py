@@ -51,6 +51,24 @@ def test_forward_random_clouds(B, N, M):
            rng.standard_normal((B, M, 3)).astype(np.float32))
 
 
+@pytest.mark.parametrize("N,M", [(300, 290), (642, 642), (2100, 2051)])      # waves-work-alone and tiled kernels
+def test_forward_nan_and_overflowing_coordinates_keep_indices_inside_the_cloud(N, M):
+    """A query no candidate compares below +inf against (a NaN coordinate, or coordinates so large
+    that every squared distance overflows) reports distance +inf and index 0, whichever kernel the
+    size picks; NaN candidates are never chosen.  Callers gather with these indices."""
+    rng = np.random.default_rng(N + M)
+    a = rng.standard_normal((2, N, 3)).astype(np.float32)
+    b = rng.standard_normal((2, M, 3)).astype(np.float32)
+    a[0, 5, 1] = np.nan                     # a NaN query / candidate
+    a[1, N - 1, :] = 3e19                   # every distance from and to it overflows to +inf
+    b[0, 7, 2] = np.nan
+    b[1, 0, 0] = np.nan                     # candidate 0 itself is NaN: still the answer for hopeless queries
+    d1, d2, i1, i2 = _check(a, b)
+    assert i1.min() >= 0 and i1.max() < M and i2.min() >= 0 and i2.max() < N
+    assert np.isinf(d1[0, 5]) and i1[0, 5] == 0 and np.isinf(d1[1, N - 1]) and i1[1, N - 1] == 0
+    assert not np.any(i1[0] == 7) and not np.any(i2[0] == 5) and not np.isnan(d1).any() and not np.isnan(d2).any()
+
+
 def test_forward_ties_duplicates_and_zero_distances():
     lat = np.stack(np.meshgrid(np.arange(8), np.arange(8), np.arange(8), indexing="ij"), -1)
     lat = lat.reshape(1, -1, 3).astype(np.float32)                      # 512 lattice points

@@ -200,7 +200,7 @@ def test_c_abi_exports_every_declared_symbol():
     lib = ctypes.CDLL(_lib.LIB_PATH)
     for name in declared:
         assert hasattr(lib, name), name
-    assert _lib.lib().sv3d_abi_version() == 2
+    assert _lib.lib().sv3d_abi_version() == 3
     assert b"workspace" in _lib.lib().sv3d_strerror(-3)
 
 

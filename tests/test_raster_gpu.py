@@ -33,11 +33,10 @@ _LOG = []
 def backward_enumeration(request):
     """Every test of this file runs with both forms of the backward's pixel enumeration (whole
     boxes, row intervals); left to itself the library picks one per launch."""
-    from sv3d import _lib as L
-    lib = L.lib()
-    assert lib.sv3d_raster_backward_spans(1 if request.param == "spans" else 0) == 0
+    from sv3d import ops
+    prev = ops.set_backward_enumeration("intervals" if request.param == "spans" else "boxes")
     yield request.param
-    assert lib.sv3d_raster_backward_spans(-1) == 0
+    ops.set_backward_enumeration(prev)
 
 
 def _record(name, **kw):
@@ -545,8 +544,7 @@ def test_backward_enumerations_agree_on_a_large_raster(mode, backward_enumeratio
     if backward_enumeration != "spans":
         pytest.skip("compares the two enumerations itself")
     import sv3d
-    from sv3d import _lib as L
-    lib = L.lib()
+    from sv3d import ops
     fv = torch.tensor([[
         [[-0.95, -0.90, 3.0], [0.92, -0.70, 3.2], [-0.20, 0.93, 2.9]],
         [[-0.90, 0.80, 2.5], [0.95, 0.805, 2.6], [0.30, -0.85, 2.4]],
@@ -558,7 +556,7 @@ def test_backward_enumerations_agree_on_a_large_raster(mode, backward_enumeratio
     grad = (2 * torch.rand(1, 4, img, img, generator=torch.Generator().manual_seed(11)) - 1).cuda()
 
     def run(spans):
-        assert lib.sv3d_raster_backward_spans(spans) == 0
+        ops.set_backward_enumeration("intervals" if spans else "boxes")
         x = fv.cuda().requires_grad_(True)
         t = tex.cuda().requires_grad_(True) if tex is not None else None
         rgba = sv3d.soft_rasterize(x, t, img, anti_aliasing=False, texture_type="surface", sigma_val=1e-5,

@@ -1,5 +1,7 @@
 """bench.py's output contract on the GPU: one JSON line with the metric, the roofline object and
-the CPU baseline, produced by a short run of the default workload."""
+the CPU baseline, produced by a short run of the default workload.  These tests start processes
+and depend on their timing, so the file is collected after the parity tests (pytest collects
+files in name order)."""
 import json
 import os
 import subprocess
@@ -28,6 +30,12 @@ def test_bench_prints_one_json_line_with_roofline_and_cpu_baseline():
     r = j["roofline"]
     assert r["bound"] in ("hbm", "mfma", "valu") and r["unit"] == "TFLOP/s"
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0 < r["frac"] < 1
+    # the kernel durations come from a pass of their own (>= 50 launches per kernel) and must fit
+    # inside the step they are part of: forward + backward kernel <= the measured step
+    k = r["other_kernel"]
+    assert r["kernel_time_samples"] >= 50 and r["avg_kernel_ms"] == max(k["fwd_ms"], k["bwd_ms"])
+    assert 0 < k["fwd_ms"] + k["bwd_ms"] <= 1.05 * j["ms_per_step"], (k, j["ms_per_step"])
+    assert j["config"]["image_planes"].startswith("alpha only")
     c = j["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
     legs = c["reference_config"]
@@ -37,6 +45,15 @@ def test_bench_prints_one_json_line_with_roofline_and_cpu_baseline():
     t = j["train_step"]
     assert t["ranks"] == 1 and t["steps"] == 4 and t["dataset_images_per_s"] > 10
     assert t["hip_graph"]["dataset_images_per_s"] > 10 and t["hip_graph"]["ms_per_step"] > 0
+    assert t["gradient_all_reduce"].startswith("none")
+    v = t["variants"]
+    assert v["hd_mesh"]["dataset_images_per_s"] > 5 and v["batch64_one_hypothesis"]["dataset_images_per_s"] > 50
+    c = j["configs"]
+    for name in ("hd_surface_rgb", "part_maps_8_per_pass"):
+        assert c[name]["images_per_s"] > 1e3 and 0 < c[name]["frac"] < 1 and c[name]["dominant_kernel"].startswith("raster_")
+        assert c[name]["fwd_kernel_ms"] + c[name]["bwd_kernel_ms"] <= 1.05 * c[name]["ms_per_step"]
+    assert "5120 faces" in c["hd_surface_rgb"]["workload"]
+    assert c["chamfer_16x8192"]["cloud_pairs_per_s"] > 100 and 0 < c["chamfer_16x8192"]["frac"] < 1
 
 
 @pytest.mark.gpu
@@ -60,3 +77,26 @@ def test_bench_two_ranks_rehearsal_prints_the_headline_and_the_train_step_under_
     t = j["train_step"]
     assert t["ranks"] == 2 and t["steps"] == 2 and "2 ranks" in t["gradient_all_reduce"]
     assert t["dataset_images_per_s"] == pytest.approx(2 * t["dataset_images_per_s_per_rank"])
+
+
+@pytest.mark.gpu
+def test_bench_one_rank_through_rccl_and_ddp():
+    """--force-dist under torch.distributed.run with ONE rank: the process group is opened on RCCL
+    ("nccl", bound to the GPU), the train step's networks are wrapped in DistributedDataParallel and
+    their bucketed gradient all-reduce runs over RCCL, and the group is shut down at the end -- the
+    path a multi-GPU run takes, executed on the one GPU this box has."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+           "127.0.0.1", "--master-port", "29593", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-dist",
+           "--steps", "20", "--warmup", "5", "--train-steps", "3", "--no-cpu-baseline",
+           "--train-args", "--enc_width 16"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=280, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 1 and "extras_error" not in j, out.stderr[-3000:]
+    t = j["train_step"]
+    assert t["gradient_all_reduce"] == "RCCL via DistributedDataParallel over 1 ranks", t["gradient_all_reduce"]
+    assert t["steps"] == 3 and t["dataset_images_per_s"] > 10 and t["hip_graph"] is None
+    assert "DDP over 1 rank(s), backend nccl" in out.stderr, out.stderr[-3000:]
+

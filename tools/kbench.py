@@ -85,8 +85,6 @@ def main():
         h.sv3d_raster_sizes.argtypes = [pp, ctypes.POINTER(sz), ctypes.POINTER(sz), ctypes.POINTER(sz)]
         h.sv3d_raster_forward_timed.argtypes = [pp, vp, vp, vp, vp, vp, vp, vp, vp]
         h.sv3d_raster_backward_timed.argtypes = [pp, vp, vp, vp, vp, vp, vp, vp, sz, vp, vp, vp]
-        if hasattr(h, "sv3d_raster_backward_spans"):
-            assert h.sv3d_raster_backward_spans(ctypes.c_int(args.bwd_spans)) == 0
         handles.append(h)
     ev = bench.HipEvents()
     dev = torch.device("cuda:0")
@@ -98,7 +96,8 @@ def main():
         S = img * (2 if aa else 1)
         m = {"none": 0, "surface": 1, "vertex": 2, "vertex8": 3}[mode]
         p = L.make_params(B, fv.shape[1], S, 2 if aa else 1, m, T, True, (0, 0, 0), 1, 100, 1e-3, sigma, 1e-10, 1e-4,
-                          alpha_only=bool(args.alpha_only) and mode == "none")
+                          alpha_only=bool(args.alpha_only) and mode == "none",
+                          backward_enumeration=args.bwd_spans + 1)
         # every library sizes its own buffers (builds may differ in what they keep there): take the
         # largest requirement over the libraries under test, never the in-tree library's alone
         rec_b = saved_b = ws_b = 0

@@ -8,7 +8,7 @@ shift
 out=gpurun_out/prof_$tag
 mkdir -p $out
 export TMPDIR=/tmp
-B="python bench.py --no-cpu-baseline --no-extras --steps 50 --warmup 10 --event_stride 1000 $*"
+B="python bench.py --no-cpu-baseline --no-extras --steps 50 --warmup 10 --kernel-launches 10 $*"
 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o s -- $B > $out/bench_stats.json 2> $out/stats.err || exit 1
 timeout -s KILL 120 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_INSTS_SALU --output-format csv -d $out/sq -o c -- $B > /dev/null 2> $out/sq.err || exit 1
 timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/fetch -o c -- $B > /dev/null 2> $out/fetch.err || exit 1
