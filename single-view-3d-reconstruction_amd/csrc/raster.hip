@@ -69,6 +69,9 @@ constexpr int kTile = 16;         // tile side in raster pixels
 #ifndef SV3D_LIST_CAP
 #define SV3D_LIST_CAP 128
 #endif
+#ifndef SV3D_EARLY_EXIT
+#define SV3D_EARLY_EXIT 1
+#endif
 constexpr int kListCap = SV3D_LIST_CAP;   // faces staged in LDS at a time (128 B each)
 constexpr int kRecPad4 = kRec4 + 1;       // LDS record stride (144 B): lane-strided reads are conflict free
 
@@ -94,6 +97,8 @@ struct DevParams {
     int alpha_fast;               // dist_eps so small that 1 + exp(-threshold/sigma) == 1 in fp32
     int alpha_only;               // silhouette mode: the image (and its gradient) is the alpha plane alone
     unsigned inv_F;               // floor(2^32 / F): the image of a face index by a multiply, see image_of_face
+    float c_scale;                // sqrt(log2(e) / sigma): lengths times this, squared, are exponents to base 2
+    float visit_r;                // sqrt(visit_threshold) * c_scale
 };
 
 // A parameter block read field by field from constant memory (the argument block of a kernel);
@@ -110,6 +115,7 @@ __device__ inline DevParams copy_params(ConstantParams p)
     d.margin = p->margin; d.visit_threshold = p->visit_threshold; d.l2e_over_gamma = p->l2e_over_gamma;
     d.inv_gamma = p->inv_gamma; d.inv_range = p->inv_range; d.ssum0 = p->ssum0; d.inv_S = p->inv_S;
     d.alpha_fast = p->alpha_fast; d.alpha_only = p->alpha_only; d.inv_F = p->inv_F;
+    d.c_scale = p->c_scale; d.visit_r = p->visit_r;
     return d;
 }
 
@@ -349,10 +355,19 @@ __device__ inline float cross_rounded(float ax, float ay, float bx, float by)
 }
 
 // Record of face `gid` from its three camera-space corners; zref = z of the image's first corner.
+// Edge A -> B of the oriented silhouette record: A and c times the unit direction.
+__device__ inline float4 oriented_edge(float ax, float ay, float bx, float by, float c)
+{
+    const float ex = bx - ax, ey = by - ay;
+    const float len2 = ex * ex + ey * ey;
+    const float inv_len = len2 > 0.f ? 1.f / sqrtf(len2) : 0.f;
+    return make_float4(ax, ay, len2 > 0.f ? c * (ex * inv_len) : c, c * (ey * inv_len));
+}
+
 __device__ inline void setup_face(const DevParams &P, int gid, float x0, float y0, float z0, float x1,
                                   float y1, float z1, float x2, float y2, float z2, float zref,
                                   float4 *__restrict__ rec, uint2 *__restrict__ pbox, int &col0, int &col1,
-                                  int &row0, int &row1)
+                                  int &row0, int &row1, float4 *__restrict__ srec = nullptr)
 {
     const float e0x = x1 - x0, e0y = y1 - y0;
     const float e1x = x2 - x1, e1y = y2 - y1;
@@ -402,6 +417,21 @@ __device__ inline void setup_face(const DevParams &P, int gid, float x0, float y
                        __int_as_float(raw_det < 0.f ? 1 : 0), zref);
     r[7] = make_float4(__uint_as_float(box.x), __uint_as_float(box.y), e2x * inv_det, e2y * inv_det);
     pbox[gid] = box;
+    if (srec) {
+        // Oriented silhouette record (per-tile lists): the three edges taken so that the inside is on
+        // their left -- for a face of the other orientation the corners go round the other way --
+        // each as its start point and c times its unit direction, c = sqrt(log2(e) / sigma).
+        float4 *q = srec + (size_t)gid * 3;
+        if (raw_det > 0.f) {
+            q[0] = oriented_edge(x0, y0, x1, y1, P.c_scale);
+            q[1] = oriented_edge(x1, y1, x2, y2, P.c_scale);
+            q[2] = oriented_edge(x2, y2, x0, y0, P.c_scale);
+        } else {
+            q[0] = oriented_edge(x0, y0, x2, y2, P.c_scale);
+            q[1] = oriented_edge(x2, y2, x1, y1, P.c_scale);
+            q[2] = oriented_edge(x1, y1, x0, y0, P.c_scale);
+        }
+    }
 }
 
 // The setup kernels run on a (faces, image) grid, so that a wave holds 64 consecutive faces of
@@ -430,7 +460,8 @@ __device__ inline void store_group_box(const DevParams &P, int b, int f, bool va
 
 __global__ __launch_bounds__(kThreads) void raster_setup_kernel(
     DevParams P, const float *__restrict__ fv, float4 *__restrict__ rec, uint2 *__restrict__ pbox,
-    uint2 *__restrict__ gbox)                   // gbox == nullptr: the forward will not read group boxes
+    uint2 *__restrict__ gbox,                   // gbox == nullptr: the forward will not read group boxes
+    float4 *__restrict__ srec)                  // oriented silhouette records, or nullptr
 {
     const int b = blockIdx.y, f = blockIdx.x * kThreads + threadIdx.x;
     const bool valid = f < P.F;
@@ -439,7 +470,7 @@ __global__ __launch_bounds__(kThreads) void raster_setup_kernel(
         const int gid = b * P.F + f;
         const float *v = fv + (size_t)gid * 9;
         setup_face(P, gid, v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], v[8],
-                   fv[(size_t)b * P.F * 9 + 2], rec, pbox, col0, col1, row0, row1);
+                   fv[(size_t)b * P.F * 9 + 2], rec, pbox, col0, col1, row0, row1, srec);
     }
     if (gbox) store_group_box(P, b, f, valid, col0, col1, row0, row1, gbox);
 }
@@ -457,7 +488,7 @@ struct MeshArgs {
 
 __global__ __launch_bounds__(kThreads) void raster_setup_mesh_kernel(
     DevParams P, MeshArgs m, float *__restrict__ fv_out, float4 *__restrict__ rec,
-    uint2 *__restrict__ pbox, uint2 *__restrict__ gbox)
+    uint2 *__restrict__ pbox, uint2 *__restrict__ gbox, float4 *__restrict__ srec)
 {
     const int b = blockIdx.y, f = blockIdx.x * kThreads + threadIdx.x;
     const bool valid = f < P.F;
@@ -482,7 +513,7 @@ __global__ __launch_bounds__(kThreads) void raster_setup_mesh_kernel(
         for (int i = 0; i < 9; ++i) fv_out[(size_t)gid * 9 + i] = o[i];
     }
     setup_face(P, gid, o[0], o[1], o[2], o[3], o[4], o[5], o[6], o[7], o[8], zref, rec, pbox, col0, col1,
-               row0, row1);
+               row0, row1, srec);
     }
     if (gbox) store_group_box(P, b, f, valid, col0, col1, row0, row1, gbox);
 }
@@ -734,7 +765,10 @@ __attribute__((amdgpu_waves_per_eu(MODE == SV3D_TEX_VERTEX8 ? 7 : 8))) void rast
         return ok;
     };
 
-    auto process_list = [&](int n) {
+    // `last`: no window follows this one, so nothing will overwrite the staged records; a wave that
+    // has walked its hits then goes straight to its epilogue instead of waiting for the tile's
+    // slowest wave (SPLIT == 2 still meets its partner: the merge below reuses the records' LDS).
+    auto process_list = [&](int n, bool last) {
         SV3D_STAMP(3);
         for (int i = threadIdx.x; i < n * kRec4; i += NT)
             s_rec[(i / kRec4) * kRecPad4 + (i % kRec4)] = rec_b[(size_t)s_ids[i / kRec4] * kRec4 + (i % kRec4)];
@@ -795,7 +829,7 @@ __attribute__((amdgpu_waves_per_eu(MODE == SV3D_TEX_VERTEX8 ? 7 : 8))) void rast
                 }
             }
         }
-        __syncthreads();
+        if (!SV3D_EARLY_EXIT || !last || SPLIT == 2) __syncthreads();
     };
 
     // ---- binning: the faces whose pixel box touches this tile, in face order ----------------
@@ -909,9 +943,9 @@ __attribute__((amdgpu_waves_per_eu(MODE == SV3D_TEX_VERTEX8 ? 7 : 8))) void rast
                 }
             }
             __syncthreads();
-            process_list(min(kListCap, total - win));
+            process_list(min(kListCap, total - win), win + kListCap >= total && fbase + 64 * 64 >= ncand);
         }
-        __syncthreads();
+        if (!SV3D_EARLY_EXIT || fbase + 64 * 64 < ncand) __syncthreads();
     }
 
     if (SPLIT == 2) {
@@ -1005,6 +1039,254 @@ __attribute__((amdgpu_waves_per_eu(MODE == SV3D_TEX_VERTEX8 ? 7 : 8))) void rast
         t[3] = (unsigned long long)trace_visits;
     }
 #endif
+}
+
+
+// ------------------------------------------------------------------------------------
+// per-tile face lists (large silhouette launches)
+// ------------------------------------------------------------------------------------
+// For large launches the per-tile work of the forward that is not fragment arithmetic -- every tile
+// testing the boxes of its image's faces, numbering its hits, copying their 128-byte records and
+// testing each against its four blocks -- is nearly half of the kernel's instructions.  Here a
+// kernel of its own makes, per tile, the ordered list of the faces whose pixel box touches it, and
+// stores for each a compact record RELATIVE TO THE TILE'S CENTRE that the fragment loop can use
+// as it is.  One workgroup per (image, bin of 4x4 tiles): the bin's faces first (ordered
+// compaction over the image's pixel boxes, into LDS), then each of the bin's tiles against those.
+//
+// Tile-relative record (16 floats).  With c = sqrt(log2(e) / sigma), for each edge k taken from A
+// to B so that the face's inside is on its left (the two are swapped for faces of the other
+// orientation), u = its unit direction, and a pixel centre x = tile centre + o:
+//     s  = c u.(x - A) = S0 + Sx ox + Sy oy       along the edge from A,   (Sx, Sy) = c u
+//     s2 = c u.(x - B) = S1 + Sx ox + Sy oy       along the edge from B  (= s - c |e|, but formed
+//                                                 from B itself: no cancellation near B)
+//     h  = c n.(x - A) = H0 - Sy ox + Sx oy       across the edge, > 0 inside,  n = (-uy, ux)
+// The squared distance to the segment, times log2(e)/sigma, is h^2 + max(-s, s2, 0)^2: 9
+// multiply-adds and selects per edge where the point-to-segment form on absolute coordinates takes
+// 14, and the pixel is inside the face iff min(h0, h1, h2) > 0.  o is exact in fp32 (a small odd
+// multiple of 1/S), and S0, S1, H0 come from centre - A formed with one rounding, so the 1/sigma
+// slope acts on numbers no larger than the tile.
+// Layout: [Sx0 Sy0 S00 S10] [H00 Sx1 Sy1 S01] [S11 H01 Sx2 Sy2] [S02 S12 H02 box], box = the
+// face's pixel box inside the tile, four 4-bit fields (col0, col1, row0, row1; 0..15).
+constexpr int kTileCap = 128;                   // records per tile slot
+
+constexpr int kTRecPad4 = 5;                    // LDS stride (80 B): lane-strided b128 reads are conflict free
+
+constexpr int kListThreads = 1024;              // sixteen waves: one per tile of the bin in the second phase
+
+__global__ __launch_bounds__(kListThreads) void raster_tile_lists_kernel(
+    DevParams P, const uint2 *__restrict__ pbox, int *__restrict__ tcount, unsigned short *__restrict__ tlist,
+    int bins_x, int tiles_x)
+{
+    extern __shared__ uint2 s_dyn_list[];       // per face of the bin: its pixel box, then the ids (16 bits each)
+    __shared__ int s_cnt[kListThreads / 64];
+    uint2 *s_box = s_dyn_list;
+    unsigned short *s_id = reinterpret_cast<unsigned short *>(s_dyn_list + P.F);
+    const int b = blockIdx.y, bin = blockIdx.x;
+    const int by = bin / bins_x, bx = bin - by * bins_x;
+    const int c0 = bx * kBinPix, c1 = c0 + kBinPix - 1, r0 = by * kBinPix, r1 = r0 + kBinPix - 1;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int NW = kListThreads / 64;
+    const unsigned long long lane_lt = (1ull << lane) - 1ull;
+    const uint2 *pb = pbox + (size_t)b * P.F;
+    int base = 0;                               // hits so far (uniform over the workgroup)
+    for (int f0 = 0; f0 < P.F; f0 += kListThreads) {
+        const int f = f0 + threadIdx.x;
+        const uint2 box = f < P.F ? pb[f] : make_uint2(0xffff7fffu, 0xffff7fffu);
+        int a0, a1, b0, b1;
+        unpack_box(box, a0, a1, b0, b1);
+        const unsigned long long mask = __ballot(!(a1 < c0 || a0 > c1 || b1 < r0 || b0 > r1));
+        if (lane == 0) s_cnt[wave] = __popcll(mask);
+        __syncthreads();
+        int off = base, total = 0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {          // face order: wave, then lane
+            const int cw = s_cnt[w];
+            off += w < wave ? cw : 0;
+            total += cw;
+        }
+        if ((mask >> lane) & 1ull) {
+            const int pos = off + __popcll(mask & lane_lt);
+            s_box[pos] = box;
+            s_id[pos] = (unsigned short)f;
+        }
+        base += total;
+        __syncthreads();
+    }
+    const int nbin = base;
+    const int t = wave;                                             // one wave per tile of the bin
+    const int tx = bx * kBinTiles + (t & (kBinTiles - 1)), ty = by * kBinTiles + t / kBinTiles;
+    if (tx >= tiles_x || ty >= tiles_x) return;                     // whole wave; no barrier follows
+    const int tc0 = tx * kTile, tr0 = ty * kTile, tc1 = tc0 + kTile - 1, tr1 = tr0 + kTile - 1;
+    const size_t tile = ((size_t)b * tiles_x + ty) * tiles_x + tx;
+    unsigned short *slot = tlist + tile * kTileCap;
+    int n = 0;
+    for (int j0 = 0; j0 < nbin; j0 += 64) {
+        const int j = j0 + lane;
+        const uint2 box = j < nbin ? s_box[j] : make_uint2(0xffff7fffu, 0xffff7fffu);
+        int a0, a1, b0, b1;
+        unpack_box(box, a0, a1, b0, b1);
+        const bool hit = !(a1 < tc0 || a0 > tc1 || b1 < tr0 || b0 > tr1);
+        const unsigned long long mask = __ballot(hit);
+        const int pos = n + __popcll(mask & lane_lt);
+        if (hit && pos < kTileCap) slot[pos] = s_id[j];
+        n += __popcll(mask);
+    }
+    if (lane == 0) tcount[tile] = n;
+}
+
+// The silhouette forward over per-tile lists: one workgroup per 16x16 tile, one wave per 8x8
+// block.  A tile without faces writes its background and is done after one scalar load; the others
+// copy their records into LDS (one trip to memory, one barrier), and every wave tests the list
+// against its block lane-parallel and walks its hits.
+// Tile-relative record of a face from its oriented silhouette record (e_k = Ax, Ay, Sx, Sy; the end
+// of edge k is the start of edge k+1) and pixel box.  (cx_num, cy_num): numerators over S of the
+// tile centre, which lies between pixel columns tc0+7 / tc0+8 and rows tr0+7 / tr0+8.
+__device__ inline void make_tile_record(const float4 e0, const float4 e1, const float4 e2, uint2 box, int tc0, int tr0,
+                                        float cx_num, float cy_num, float fS, float inv_S, float4 *__restrict__ o)
+{
+    // centre - A with one rounding: centre = num / S with num an integer, so (num - A S) / S
+    const float d0x = fmaf(-e0.x, fS, cx_num) * inv_S, d0y = fmaf(-e0.y, fS, cy_num) * inv_S;
+    const float d1x = fmaf(-e1.x, fS, cx_num) * inv_S, d1y = fmaf(-e1.y, fS, cy_num) * inv_S;
+    const float d2x = fmaf(-e2.x, fS, cx_num) * inv_S, d2y = fmaf(-e2.y, fS, cy_num) * inv_S;
+    int a0, a1, b0, b1;
+    unpack_box(box, a0, a1, b0, b1);
+    const unsigned bits = (unsigned)min(max(a0 - tc0, 0), 15) | ((unsigned)min(max(a1 - tc0, 0), 15) << 4) |
+                          ((unsigned)min(max(b0 - tr0, 0), 15) << 8) | ((unsigned)min(max(b1 - tr0, 0), 15) << 12);
+    // per edge: Sx, Sy, S0 = S.(centre - A), S1 = S.(centre - B), H0 = n.(centre - A), n = (-Sy, Sx)
+    o[0] = make_float4(e0.z, e0.w, fmaf(e0.z, d0x, e0.w * d0y), fmaf(e0.z, d1x, e0.w * d1y));
+    o[1] = make_float4(fmaf(-e0.w, d0x, e0.z * d0y), e1.z, e1.w, fmaf(e1.z, d1x, e1.w * d1y));
+    o[2] = make_float4(fmaf(e1.z, d2x, e1.w * d2y), fmaf(-e1.w, d1x, e1.z * d1y), e2.z, e2.w);
+    o[3] = make_float4(fmaf(e2.z, d2x, e2.w * d2y), fmaf(e2.z, d0x, e2.w * d0y), fmaf(-e2.w, d2x, e2.z * d2y),
+                       __uint_as_float(bits));
+}
+
+__global__ __launch_bounds__(kThreads) void raster_forward_tiled_kernel(
+    const int *__restrict__ tcount, const unsigned short *__restrict__ tlist, const float4 *__restrict__ srec,
+    const uint2 *__restrict__ pbox, int num_faces, float *__restrict__ rgba, float *__restrict__ saved, DevParams P)
+{
+    __shared__ float4 s_trec[kTileCap * kTRecPad4];
+    const int tiles_x = (P.S + kTile - 1) / kTile;
+    const int b = blockIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int tile_x, tile_y;
+    tile_position(blockIdx.y, blockIdx.z, tiles_x, false, tile_x, tile_y);
+    const size_t tile = ((size_t)b * tiles_x + tile_y) * tiles_x + tile_x;
+    const int n_list = tcount[tile];
+    const int S = P.S, F = num_faces;
+    const int tile_c0 = tile_x * kTile, tile_r0 = tile_y * kTile;
+    const int quad = lane >> 2, sub = lane & 3;
+    const int blk = wave;
+    const int lc = (blk & 1) * 8 + (quad & 3) * 2 + (sub & 1), lr = (blk >> 1) * 8 + (quad >> 2) * 2 + (sub >> 1);
+    const int col = tile_c0 + lc, row = tile_r0 + lr;
+    float A = 1.f;
+    if (n_list > 0) {                                                   // uniform over the workgroup
+        // pixel centre relative to the tile centre: odd multiples of 1/S, exact when S is a power of two
+        // (otherwise rounded by 6e-8 of at most 15/S: a thirtieth of what rounding the centre itself costs)
+        const float ox = (float)(2 * lc - (kTile - 1)) * P.inv_S, oy = -(float)(2 * lr - (kTile - 1)) * P.inv_S;
+        // block centre and half extent (between its outermost pixel centres)
+        const float bcx = (blk & 1) ? 8.f * P.inv_S : -8.f * P.inv_S, bcy = (blk >> 1) ? -8.f * P.inv_S : 8.f * P.inv_S;
+        const float bh = 7.f * P.inv_S;
+        const int bc0 = (blk & 1) * 8, br0 = (blk >> 1) * 8;
+        const float cx_num = (float)(2 * tile_c0 + kTile - S), cy_num = (float)(S - kTile - 2 * tile_r0);
+        constexpr unsigned kNoFace = 1u << 16;                          // record slot without a face
+
+        // the records s_trec[0 .. nw) against this wave's block, and its hits
+        auto process_window = [&](int nw, bool last) {
+            __syncthreads();
+            for (int j0 = 0; j0 < nw; j0 += 64) {
+                const int j = j0 + lane;
+                bool hit = false;
+                if (j < nw) {
+                    const float4 *r = &s_trec[j * kTRecPad4];
+                    const float4 r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3];
+                    const unsigned bits = __float_as_uint(r3.w);
+                    const int fc0 = bits & 15, fc1 = (bits >> 4) & 15, fr0 = (bits >> 8) & 15, fr1 = (bits >> 12) & 15;
+                    hit = bits < kNoFace && !(fc1 < bc0 || fc0 > bc0 + 7 || fr1 < br0 || fr0 > br0 + 7);
+                    // the largest h over the block, per edge: behind an edge line by more than the visit
+                    // distance everywhere means that this face changes no pixel of the block
+                    const float h0 = fmaf(-r0.y, bcx, fmaf(r0.x, bcy, r1.x)) + (fabsf(r0.x) + fabsf(r0.y)) * bh;
+                    const float h1 = fmaf(-r1.z, bcx, fmaf(r1.y, bcy, r2.y)) + (fabsf(r1.y) + fabsf(r1.z)) * bh;
+                    const float h2 = fmaf(-r2.w, bcx, fmaf(r2.z, bcy, r3.z)) + (fabsf(r2.z) + fabsf(r2.w)) * bh;
+                    hit = hit && fminf(h0, fminf(h1, h2)) >= -P.visit_r;
+                }
+                unsigned long long mask = __ballot(hit);
+                while (mask) {
+                    const int jj = j0 + __builtin_ctzll(mask);
+                    mask &= mask - 1;
+                    const float4 *r = &s_trec[jj * kTRecPad4];
+                    const float4 r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3];
+                    // along each edge (shared part), across it, beyond its ends
+                    const float q0 = fmaf(r0.x, ox, r0.y * oy), q1 = fmaf(r1.y, ox, r1.z * oy), q2 = fmaf(r2.z, ox, r2.w * oy);
+                    const float h0 = fmaf(-r0.y, ox, fmaf(r0.x, oy, r1.x));
+                    const float h1 = fmaf(-r1.z, ox, fmaf(r1.y, oy, r2.y));
+                    const float h2 = fmaf(-r2.w, ox, fmaf(r2.z, oy, r3.z));
+                    const float o0 = fmaxf(fmaxf(-(q0 + r0.z), q0 + r0.w), 0.f);
+                    const float o1 = fmaxf(fmaxf(-(q1 + r1.w), q1 + r2.x), 0.f);
+                    const float o2 = fmaxf(fmaxf(-(q2 + r3.x), q2 + r3.y), 0.f);
+                    const float dd = fminf(fmaf(o0, o0, h0 * h0), fminf(fmaf(o1, o1, h1 * h1), fmaf(o2, o2, h2 * h2)));
+                    const bool inside = fminf(h0, fminf(h1, h2)) > 0.f;
+                    // 1 - D = 1 / (1 + exp(+-d2 / sigma)), + inside: see pair_one_minus_D
+                    A *= rcp(1.f + ex2(inside ? dd : -dd));
+                }
+            }
+            if (!last) __syncthreads();
+        };
+
+        if (n_list <= kTileCap) {
+            if ((int)threadIdx.x < n_list) {    // one thread per face of the list builds its record in LDS
+                const size_t f = (size_t)b * F + tlist[tile * kTileCap + threadIdx.x];
+                const float4 *q = srec + f * 3;
+                make_tile_record(q[0], q[1], q[2], pbox[f], tile_c0, tile_r0, cx_num, cy_num, (float)S, P.inv_S,
+                                 &s_trec[threadIdx.x * kTRecPad4]);
+            }
+            process_window(n_list, true);
+        } else {
+            // More faces than a list holds (a dense mesh drawn small): the tile goes through all of
+            // the image's faces itself, a window of slots at a time, in face order.
+            const int tc1 = tile_c0 + kTile - 1, tr1 = tile_r0 + kTile - 1;
+            for (int f0 = 0; f0 < F; f0 += kTileCap) {                  // uniform over the workgroup
+                const int nw = min(kTileCap, F - f0);
+                if ((int)threadIdx.x < nw) {
+                    const size_t f = (size_t)b * F + f0 + threadIdx.x;
+                    const uint2 box = pbox[f];
+                    int a0, a1, b0, b1;
+                    unpack_box(box, a0, a1, b0, b1);
+                    float4 *o = &s_trec[threadIdx.x * kTRecPad4];
+                    if (!(a1 < tile_c0 || a0 > tc1 || b1 < tile_r0 || b0 > tr1)) {
+                        const float4 *q = srec + f * 3;
+                        make_tile_record(q[0], q[1], q[2], box, tile_c0, tile_r0, cx_num, cy_num, (float)S, P.inv_S, o);
+                    } else {
+                        o[3].w = __uint_as_float(kNoFace);
+                    }
+                }
+                process_window(nw, f0 + kTileCap >= F);
+            }
+        }
+    }
+    A = fminf(A, 1.f);
+    const float alpha = 1.f - A;
+    const bool inimg = col < S && row < S;
+    if (inimg) saved[((size_t)b * S + row) * S + col] = A;
+    const bool only_alpha = P.alpha_only;
+    const int planes = only_alpha ? 1 : 4;
+    if (P.aa == 2) {
+        const int H = S >> 1;
+        const size_t plane = (size_t)H * H;
+        const size_t ob = ((size_t)b * planes * H + (row >> 1)) * H + (col >> 1);
+        float v = inimg ? alpha : 0.f;
+        v += __shfl_xor(v, 1);
+        v += __shfl_xor(v, 2);
+        if (sub == 0 && inimg) {
+            rgba[ob + (planes - 1) * plane] = 0.25f * v;
+            if (!only_alpha) { rgba[ob] = P.bg0; rgba[ob + plane] = P.bg1; rgba[ob + 2 * plane] = P.bg2; }
+        }
+    } else if (inimg) {
+        const size_t plane = (size_t)S * S;
+        const size_t ob = ((size_t)b * planes * S + row) * S + col;
+        rgba[ob + (planes - 1) * plane] = alpha;
+        if (!only_alpha) { rgba[ob] = P.bg0; rgba[ob + plane] = P.bg1; rgba[ob + 2 * plane] = P.bg2; }
+    }
 }
 
 // ------------------------------------------------------------------------------------
@@ -1629,6 +1911,8 @@ int make_dev_params(const sv3d_raster_params *p, DevParams &d)
     const double exact_one = 17.5 * (double)p->sigma;
     d.visit_threshold = (d.mode == SV3D_TEX_NONE && d.alpha_fast && exact_one < thr) ? (float)exact_one : d.threshold;
     d.alpha_only = p->alpha_only;
+    d.c_scale = (float)sqrt(l2e / (double)p->sigma);
+    d.visit_r = (float)sqrt((double)d.visit_threshold * l2e / (double)p->sigma);
     d.inv_F = p->num_faces == 1 ? 0xffffffffu : (unsigned)(0x100000000ull / (unsigned long long)p->num_faces);
     return SV3D_OK;
 }
@@ -1647,7 +1931,10 @@ inline size_t backward_ws_need(const DevParams &)
 
 // Coarse bins are built for meshes with many faces (ids must fit 16 bits); their storage follows the
 // pixel boxes in the face_rec buffer: counts [B][nbins] int32, then lists [B][nbins][cap] uint16.
-inline bool coarse_enabled(const DevParams &d) { return d.F >= 2048 && d.F <= 65535 && d.S > kBinPix; }
+#ifndef SV3D_COARSE_MIN_FACES
+#define SV3D_COARSE_MIN_FACES 2048
+#endif
+inline bool coarse_enabled(const DevParams &d) { return d.F >= SV3D_COARSE_MIN_FACES && d.F <= 65535 && d.S > kBinPix; }
 inline int coarse_bins_x(const DevParams &d) { return (d.S + kBinPix - 1) / kBinPix; }
 inline int coarse_cap(const DevParams &d) { return (d.F + 7) & ~7; }
 inline size_t coarse_bytes(const DevParams &d)
@@ -1655,6 +1942,25 @@ inline size_t coarse_bytes(const DevParams &d)
     if (!coarse_enabled(d)) return 0;
     const size_t nb = (size_t)d.B * coarse_bins_x(d) * coarse_bins_x(d);
     return nb * sizeof(int) + nb * coarse_cap(d) * sizeof(unsigned short);
+}
+
+// Per-tile lists: large silhouette launches whose tile, scaled by sqrt(log2(e)/sigma), is small enough
+// for the tile-relative evaluation to stay within the rounding the absolute one has.
+#ifndef SV3D_TILED
+#define SV3D_TILED 1
+#endif
+inline bool tiled_enabled(const DevParams &d)
+{
+    const long tiles = (d.S + kTile - 1) / kTile;
+    return SV3D_TILED && d.mode == SV3D_TEX_NONE && d.alpha_fast && tiles * tiles * d.B > SV3D_SPLIT_MAX_TILES &&
+           d.F <= 6000 && d.c_scale * (float)kTile * d.inv_S <= 64.f;
+}
+inline size_t tiled_bytes(const DevParams &d)
+{
+    if (!tiled_enabled(d)) return 0;
+    const size_t tiles = (size_t)((d.S + kTile - 1) / kTile);
+    const size_t nt = (size_t)d.B * tiles * tiles;
+    return nt * sizeof(int) + 16 + (size_t)d.B * d.F * 3 * sizeof(float4) + nt * kTileCap * sizeof(unsigned short);
 }
 
 inline int launch_status()
@@ -1673,7 +1979,7 @@ extern "C" int sv3d_raster_sizes(const sv3d_raster_params *p, size_t *face_rec_b
     const size_t pix = (size_t)d.B * d.S * d.S * saved_per_pixel(d) * sizeof(float);
     if (face_rec_bytes)
         *face_rec_bytes = rec_floats(d) * sizeof(float) + ((size_t)d.B * d.F + group_boxes(d)) * sizeof(uint2) +
-                          coarse_bytes(d);
+                          coarse_bytes(d) + tiled_bytes(d);
     if (pixel_saved_bytes) *pixel_saved_bytes = pix;
     if (backward_ws_bytes) *backward_ws_bytes = backward_ws_need(d);
     return SV3D_OK;
@@ -1712,15 +2018,28 @@ int raster_forward_impl(const sv3d_raster_params *p, const float *face_vertices,
     const bool split = (long)tiles * tiles * d.B <= SV3D_SPLIT_MAX_TILES;      // measured: 12 and 16 images of 256^2 are faster unsplit
     // group boxes are read by the large launches without coarse bins only
     uint2 *gbox_setup = (!coarse && !(SV3D_DIRECT_BOXES && split)) ? gbox : nullptr;
+    // per-tile lists: counts [B][tiles][tiles], then (16-byte aligned) the faces' oriented silhouette
+    // records, then the tiles' lists of face ids
+    const bool tiled = tiled_enabled(d);
+    int *tcount = nullptr;
+    float4 *srec = nullptr;
+    unsigned short *tlist = nullptr;
+    if (tiled) {
+        const size_t nt = (size_t)d.B * tiles * tiles;
+        char *tbase = reinterpret_cast<char *>(gbox + group_boxes(d)) + coarse_bytes(d);
+        tcount = reinterpret_cast<int *>(tbase);
+        srec = reinterpret_cast<float4 *>((reinterpret_cast<uintptr_t>(tbase + nt * sizeof(int)) + 15) & ~(uintptr_t)15);
+        tlist = reinterpret_cast<unsigned short *>(srec + (size_t)d.B * d.F * 3);
+    }
     if (mesh) {
         MeshArgs m;
         m.vertices = mesh->vertices; m.cams = mesh->cams; m.faces = mesh->faces;
         m.V = mesh->num_vertices; m.faces_batch = mesh->faces_batch; m.offset_z = mesh->offset_z;
         m.a = {mesh->scale[0], mesh->scale[1], mesh->scale[2], mesh->shift[0], mesh->shift[1], mesh->shift[2]};
         hipLaunchKernelGGL(raster_setup_mesh_kernel, sgrid, dim3(kThreads), 0, s, d, m,
-                           const_cast<float *>(face_vertices), rec, pbox, gbox_setup);
+                           const_cast<float *>(face_vertices), rec, pbox, gbox_setup, srec);
     } else {
-        hipLaunchKernelGGL(raster_setup_kernel, sgrid, dim3(kThreads), 0, s, d, face_vertices, rec, pbox, gbox_setup);
+        hipLaunchKernelGGL(raster_setup_kernel, sgrid, dim3(kThreads), 0, s, d, face_vertices, rec, pbox, gbox_setup, srec);
     }
     float *saved = static_cast<float *>(pixel_saved);
     CoarseBins cb = {nullptr, nullptr, 0, 0, 0};
@@ -1731,6 +2050,18 @@ int raster_forward_impl(const sv3d_raster_params *p, const float *face_vertices,
         hipLaunchKernelGGL(raster_coarse_kernel, dim3((unsigned)(d.B * nbins)), dim3(kThreads), 0, s, d, pbox,
                            list, count, bx, nbins, cap);
         cb = {list, count, bx, nbins, cap};
+    }
+    if (tiled) {
+        const int bx = coarse_bins_x(d);
+        hipLaunchKernelGGL(raster_tile_lists_kernel, dim3((unsigned)(bx * bx), (unsigned)d.B), dim3(kListThreads),
+                           (size_t)d.F * (sizeof(uint2) + sizeof(unsigned short)), s, d, pbox, tcount, tlist, bx, tiles);
+        if (ev_start) (void)hipEventRecord(ev_start, s);
+        const dim3 tgrid((unsigned)d.B, (unsigned)tiles, (unsigned)tiles);
+        for (int rep = 0; rep < repeats; ++rep)
+            hipLaunchKernelGGL(raster_forward_tiled_kernel, tgrid, dim3(kThreads), 0, s, tcount, tlist, srec, pbox, d.F,
+                               rgba_out, saved, d);
+        if (ev_stop) (void)hipEventRecord(ev_stop, s);
+        return launch_status();
     }
     if (ev_start) (void)hipEventRecord(ev_start, s);
     // the remainder-carrying variants when S is not a power of two

@@ -195,3 +195,26 @@ def test_batch_40_launch_against_the_oracle(mode):
     tex = _textures(mode, B, faces.shape[0], 3)
     sampled_compare("b40_%s_128" % mode, fv, tex, 128, False, mode, 384, check_images=(0, 7, 19, 32, 39),
                     sigma=1e-4, gamma=1e-3)
+
+
+def test_tiled_forward_with_more_faces_in_a_tile_than_a_list_holds():
+    """Large silhouette launches take per-tile face lists of at most 128 faces; a tile with more
+    (here the 5120-face mesh drawn a fifth of the screen wide: several hundred faces per tile)
+    goes through all faces itself.  9 images x 256 tiles: above the size where the lists start."""
+    verts, faces = load_mesh(4)
+    B = 9
+    fv = camera_space_faces(verts, faces, B, seed=12)
+    fv[..., :2] *= 0.3                                      # x, y: a small object, dense in faces
+    fv[..., 0] += 0.21
+    w = sampled_compare("tiled_overflow_hd_small_256", fv, None, 256, False, "none", 256, check_images=(0, 4, 8),
+                        sigma=1e-4)
+    assert w["img"] < TOL
+
+
+def test_tiled_forward_on_a_raster_that_is_not_a_power_of_two():
+    """Per-tile lists with partial tiles at the border and pixel centres that fp32 cannot hold
+    exactly (S = 200: 13 x 13 tiles, the last 8 pixels wide); 16 images."""
+    verts, faces = load_mesh(3)
+    B = 16
+    fv = camera_space_faces(verts, faces, B, seed=14)
+    sampled_compare("tiled_mask_200", fv, None, 200, False, "none", 256, check_images=(0, 9, 15), sigma=3e-5)
