@@ -72,6 +72,16 @@ constexpr int kTile = 16;         // tile side in raster pixels
 #ifndef SV3D_EARLY_EXIT
 #define SV3D_EARLY_EXIT 1
 #endif
+// per-tile face lists (large silhouette launches, see raster_tile_lists_kernel)
+#ifndef SV3D_TILED
+#define SV3D_TILED 1
+#endif
+#ifndef SV3D_TILED_TWO_BLOCKS_MIN_TILES
+#define SV3D_TILED_TWO_BLOCKS_MIN_TILES 12288   // two blocks per wave from this many tiles per launch
+#endif
+#ifndef SV3D_TILED_MIN_TILES
+#define SV3D_TILED_MIN_TILES 4096                   // launches above this many tiles take the lists
+#endif
 constexpr int kListCap = SV3D_LIST_CAP;   // faces staged in LDS at a time (128 B each)
 constexpr int kRecPad4 = kRec4 + 1;       // LDS record stride (144 B): lane-strided reads are conflict free
 
@@ -1134,10 +1144,6 @@ __global__ __launch_bounds__(kListThreads) void raster_tile_lists_kernel(
     if (lane == 0) tcount[tile] = n;
 }
 
-// The silhouette forward over per-tile lists: one workgroup per 16x16 tile, one wave per 8x8
-// block.  A tile without faces writes its background and is done after one scalar load; the others
-// copy their records into LDS (one trip to memory, one barrier), and every wave tests the list
-// against its block lane-parallel and walks its hits.
 // Tile-relative record of a face from its oriented silhouette record (e_k = Ax, Ay, Sx, Sy; the end
 // of edge k is the start of edge k+1) and pixel box.  (cx_num, cy_num): numerators over S of the
 // tile centre, which lies between pixel columns tc0+7 / tc0+8 and rows tr0+7 / tr0+8.
@@ -1160,7 +1166,35 @@ __device__ inline void make_tile_record(const float4 e0, const float4 e1, const 
                        __uint_as_float(bits));
 }
 
-__global__ __launch_bounds__(kThreads) void raster_forward_tiled_kernel(
+// The silhouette forward over per-tile lists: one workgroup per 16x16 tile.  A tile without faces
+// writes its background and is done after one scalar load; the others build their faces'
+// tile-relative records in LDS (one thread per face: ids, then the faces' records -- two trips to
+// memory -- and one barrier), and every wave tests the list against its 8x8 blocks lane-parallel
+// and walks its hits.
+// NB = 1: four waves, one block each.  NB = 2 (the largest launches): two waves, rows 0-7 and 8-15,
+// each wave's lanes holding one pixel of the left and one of the right block; a visit's record is
+// then read from LDS once for both blocks.  The four broadcast ds_read_b128 of a visit take 16
+// cycles of the CU's LDS array, which four SIMDs running one-block visits (70 cycles of VALU issue
+// each) keep 90 % busy: the LDS, not the VALU, bounds them.  (Fewer, longer waves: launches of fewer
+// than some ten thousand tiles, bound by their longest waves, keep one block per wave.)
+__device__ inline float tile_visit(const float4 r0, const float4 r1, const float4 r2, const float4 r3, float ox, float oy)
+{
+    // along each edge (shared part), across it, beyond its ends
+    const float q0 = fmaf(r0.x, ox, r0.y * oy), q1 = fmaf(r1.y, ox, r1.z * oy), q2 = fmaf(r2.z, ox, r2.w * oy);
+    const float h0 = fmaf(-r0.y, ox, fmaf(r0.x, oy, r1.x));
+    const float h1 = fmaf(-r1.z, ox, fmaf(r1.y, oy, r2.y));
+    const float h2 = fmaf(-r2.w, ox, fmaf(r2.z, oy, r3.z));
+    const float o0 = fmaxf(fmaxf(-(q0 + r0.z), q0 + r0.w), 0.f);
+    const float o1 = fmaxf(fmaxf(-(q1 + r1.w), q1 + r2.x), 0.f);
+    const float o2 = fmaxf(fmaxf(-(q2 + r3.x), q2 + r3.y), 0.f);
+    const float dd = fminf(fmaf(o0, o0, h0 * h0), fminf(fmaf(o1, o1, h1 * h1), fmaf(o2, o2, h2 * h2)));
+    const bool inside = fminf(h0, fminf(h1, h2)) > 0.f;
+    // 1 - D = 1 / (1 + exp(+-d2 / sigma)), + inside: see pair_one_minus_D
+    return rcp(1.f + ex2(inside ? dd : -dd));
+}
+
+template <int NB>
+__global__ __launch_bounds__(kThreads / NB) void raster_forward_tiled_kernel(
     const int *__restrict__ tcount, const unsigned short *__restrict__ tlist, const float4 *__restrict__ srec,
     const uint2 *__restrict__ pbox, int num_faces, float *__restrict__ rgba, float *__restrict__ saved, DevParams P)
 {
@@ -1176,58 +1210,57 @@ __global__ __launch_bounds__(kThreads) void raster_forward_tiled_kernel(
     const int S = P.S, F = num_faces;
     const int tile_c0 = tile_x * kTile, tile_r0 = tile_y * kTile;
     const int quad = lane >> 2, sub = lane & 3;
-    const int blk = wave;
-    const int lc = (blk & 1) * 8 + (quad & 3) * 2 + (sub & 1), lr = (blk >> 1) * 8 + (quad >> 2) * 2 + (sub >> 1);
+    // lane -> pixel (lc, lr) of the wave's (left) block, and with NB = 2 also (lc + 8, lr) of the right one
+    const int bc0 = NB == 2 ? 0 : (wave & 1) * 8, br0 = NB == 2 ? wave * 8 : (wave >> 1) * 8;
+    const int lc = bc0 + (quad & 3) * 2 + (sub & 1), lr = br0 + (quad >> 2) * 2 + (sub >> 1);
     const int col = tile_c0 + lc, row = tile_r0 + lr;
-    float A = 1.f;
+    float A0 = 1.f, A1 = 1.f;
     if (n_list > 0) {                                                   // uniform over the workgroup
-        // pixel centre relative to the tile centre: odd multiples of 1/S, exact when S is a power of two
+        // pixel centres relative to the tile centre: odd multiples of 1/S, exact when S is a power of two
         // (otherwise rounded by 6e-8 of at most 15/S: a thirtieth of what rounding the centre itself costs)
-        const float ox = (float)(2 * lc - (kTile - 1)) * P.inv_S, oy = -(float)(2 * lr - (kTile - 1)) * P.inv_S;
-        // block centre and half extent (between its outermost pixel centres)
-        const float bcx = (blk & 1) ? 8.f * P.inv_S : -8.f * P.inv_S, bcy = (blk >> 1) ? -8.f * P.inv_S : 8.f * P.inv_S;
+        const float ox0 = (float)(2 * lc - (kTile - 1)) * P.inv_S, ox1 = (float)(2 * lc + 1) * P.inv_S;
+        const float oy = -(float)(2 * lr - (kTile - 1)) * P.inv_S;
+        // block centres (-+bcx, bcy) and half extent (between the outermost pixel centres)
+        const float bcy = br0 ? -8.f * P.inv_S : 8.f * P.inv_S, bcx = 8.f * P.inv_S;
         const float bh = 7.f * P.inv_S;
-        const int bc0 = (blk & 1) * 8, br0 = (blk >> 1) * 8;
         const float cx_num = (float)(2 * tile_c0 + kTile - S), cy_num = (float)(S - kTile - 2 * tile_r0);
         constexpr unsigned kNoFace = 1u << 16;                          // record slot without a face
 
-        // the records s_trec[0 .. nw) against this wave's block, and its hits
         auto process_window = [&](int nw, bool last) {
             __syncthreads();
             for (int j0 = 0; j0 < nw; j0 += 64) {
                 const int j = j0 + lane;
-                bool hit = false;
+                bool hit0 = false, hit1 = false;
                 if (j < nw) {
                     const float4 *r = &s_trec[j * kTRecPad4];
                     const float4 r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3];
                     const unsigned bits = __float_as_uint(r3.w);
                     const int fc0 = bits & 15, fc1 = (bits >> 4) & 15, fr0 = (bits >> 8) & 15, fr1 = (bits >> 12) & 15;
-                    hit = bits < kNoFace && !(fc1 < bc0 || fc0 > bc0 + 7 || fr1 < br0 || fr0 > br0 + 7);
-                    // the largest h over the block, per edge: behind an edge line by more than the visit
+                    const bool rows = bits < kNoFace && !(fr1 < br0 || fr0 > br0 + 7);
+                    // the largest h over a block, per edge: behind an edge line by more than the visit
                     // distance everywhere means that this face changes no pixel of the block
-                    const float h0 = fmaf(-r0.y, bcx, fmaf(r0.x, bcy, r1.x)) + (fabsf(r0.x) + fabsf(r0.y)) * bh;
-                    const float h1 = fmaf(-r1.z, bcx, fmaf(r1.y, bcy, r2.y)) + (fabsf(r1.y) + fabsf(r1.z)) * bh;
-                    const float h2 = fmaf(-r2.w, bcx, fmaf(r2.z, bcy, r3.z)) + (fabsf(r2.z) + fabsf(r2.w)) * bh;
-                    hit = hit && fminf(h0, fminf(h1, h2)) >= -P.visit_r;
+                    const float m0 = (fabsf(r0.x) + fabsf(r0.y)) * bh + fmaf(r0.x, bcy, r1.x);
+                    const float m1 = (fabsf(r1.y) + fabsf(r1.z)) * bh + fmaf(r1.y, bcy, r2.y);
+                    const float m2 = (fabsf(r2.z) + fabsf(r2.w)) * bh + fmaf(r2.z, bcy, r3.z);
+                    // h changes by -Sy per unit of x: left block at -bcx, right block at +bcx
+                    const float l = fminf(fmaf(r0.y, bcx, m0), fminf(fmaf(r1.z, bcx, m1), fmaf(r2.w, bcx, m2)));
+                    const float g = fminf(fmaf(-r0.y, bcx, m0), fminf(fmaf(-r1.z, bcx, m1), fmaf(-r2.w, bcx, m2)));
+                    if (NB == 2) {
+                        hit0 = rows && fc0 <= 7 && l >= -P.visit_r;
+                        hit1 = rows && fc1 >= 8 && g >= -P.visit_r;
+                    } else {                    // the wave's one block: the left or the right one
+                        hit0 = rows && (bc0 ? fc1 >= 8 && g >= -P.visit_r : fc0 <= 7 && l >= -P.visit_r);
+                    }
                 }
-                unsigned long long mask = __ballot(hit);
+                const unsigned long long mask0 = __ballot(hit0), mask1 = __ballot(hit1);
+                unsigned long long mask = mask0 | mask1;
                 while (mask) {
-                    const int jj = j0 + __builtin_ctzll(mask);
+                    const int bit = __builtin_ctzll(mask);
                     mask &= mask - 1;
-                    const float4 *r = &s_trec[jj * kTRecPad4];
+                    const float4 *r = &s_trec[(j0 + bit) * kTRecPad4];
                     const float4 r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3];
-                    // along each edge (shared part), across it, beyond its ends
-                    const float q0 = fmaf(r0.x, ox, r0.y * oy), q1 = fmaf(r1.y, ox, r1.z * oy), q2 = fmaf(r2.z, ox, r2.w * oy);
-                    const float h0 = fmaf(-r0.y, ox, fmaf(r0.x, oy, r1.x));
-                    const float h1 = fmaf(-r1.z, ox, fmaf(r1.y, oy, r2.y));
-                    const float h2 = fmaf(-r2.w, ox, fmaf(r2.z, oy, r3.z));
-                    const float o0 = fmaxf(fmaxf(-(q0 + r0.z), q0 + r0.w), 0.f);
-                    const float o1 = fmaxf(fmaxf(-(q1 + r1.w), q1 + r2.x), 0.f);
-                    const float o2 = fmaxf(fmaxf(-(q2 + r3.x), q2 + r3.y), 0.f);
-                    const float dd = fminf(fmaf(o0, o0, h0 * h0), fminf(fmaf(o1, o1, h1 * h1), fmaf(o2, o2, h2 * h2)));
-                    const bool inside = fminf(h0, fminf(h1, h2)) > 0.f;
-                    // 1 - D = 1 / (1 + exp(+-d2 / sigma)), + inside: see pair_one_minus_D
-                    A *= rcp(1.f + ex2(inside ? dd : -dd));
+                    if (NB == 1 || ((mask0 >> bit) & 1ull)) A0 *= tile_visit(r0, r1, r2, r3, ox0, oy);
+                    if (NB == 2 && ((mask1 >> bit) & 1ull)) A1 *= tile_visit(r0, r1, r2, r3, ox1, oy);
                 }
             }
             if (!last) __syncthreads();
@@ -1264,28 +1297,32 @@ __global__ __launch_bounds__(kThreads) void raster_forward_tiled_kernel(
             }
         }
     }
-    A = fminf(A, 1.f);
-    const float alpha = 1.f - A;
-    const bool inimg = col < S && row < S;
-    if (inimg) saved[((size_t)b * S + row) * S + col] = A;
     const bool only_alpha = P.alpha_only;
     const int planes = only_alpha ? 1 : 4;
-    if (P.aa == 2) {
-        const int H = S >> 1;
-        const size_t plane = (size_t)H * H;
-        const size_t ob = ((size_t)b * planes * H + (row >> 1)) * H + (col >> 1);
-        float v = inimg ? alpha : 0.f;
-        v += __shfl_xor(v, 1);
-        v += __shfl_xor(v, 2);
-        if (sub == 0 && inimg) {
-            rgba[ob + (planes - 1) * plane] = 0.25f * v;
+#pragma unroll
+    for (int side = 0; side < NB; ++side) {
+        const float A = fminf(side ? A1 : A0, 1.f);
+        const float alpha = 1.f - A;
+        const int c = col + 8 * side;
+        const bool inimg = c < S && row < S;
+        if (inimg) saved[((size_t)b * S + row) * S + c] = A;
+        if (P.aa == 2) {
+            const int H = S >> 1;
+            const size_t plane = (size_t)H * H;
+            const size_t ob = ((size_t)b * planes * H + (row >> 1)) * H + (c >> 1);
+            float v = inimg ? alpha : 0.f;
+            v += __shfl_xor(v, 1);
+            v += __shfl_xor(v, 2);
+            if (sub == 0 && inimg) {
+                rgba[ob + (planes - 1) * plane] = 0.25f * v;
+                if (!only_alpha) { rgba[ob] = P.bg0; rgba[ob + plane] = P.bg1; rgba[ob + 2 * plane] = P.bg2; }
+            }
+        } else if (inimg) {
+            const size_t plane = (size_t)S * S;
+            const size_t ob = ((size_t)b * planes * S + row) * S + c;
+            rgba[ob + (planes - 1) * plane] = alpha;
             if (!only_alpha) { rgba[ob] = P.bg0; rgba[ob + plane] = P.bg1; rgba[ob + 2 * plane] = P.bg2; }
         }
-    } else if (inimg) {
-        const size_t plane = (size_t)S * S;
-        const size_t ob = ((size_t)b * planes * S + row) * S + col;
-        rgba[ob + (planes - 1) * plane] = alpha;
-        if (!only_alpha) { rgba[ob] = P.bg0; rgba[ob + plane] = P.bg1; rgba[ob + 2 * plane] = P.bg2; }
     }
 }
 
@@ -1946,13 +1983,10 @@ inline size_t coarse_bytes(const DevParams &d)
 
 // Per-tile lists: large silhouette launches whose tile, scaled by sqrt(log2(e)/sigma), is small enough
 // for the tile-relative evaluation to stay within the rounding the absolute one has.
-#ifndef SV3D_TILED
-#define SV3D_TILED 1
-#endif
 inline bool tiled_enabled(const DevParams &d)
 {
     const long tiles = (d.S + kTile - 1) / kTile;
-    return SV3D_TILED && d.mode == SV3D_TEX_NONE && d.alpha_fast && tiles * tiles * d.B > SV3D_SPLIT_MAX_TILES &&
+    return SV3D_TILED && d.mode == SV3D_TEX_NONE && d.alpha_fast && tiles * tiles * d.B > SV3D_TILED_MIN_TILES &&
            d.F <= 6000 && d.c_scale * (float)kTile * d.inv_S <= 64.f;
 }
 inline size_t tiled_bytes(const DevParams &d)
@@ -2057,9 +2091,15 @@ int raster_forward_impl(const sv3d_raster_params *p, const float *face_vertices,
                            (size_t)d.F * (sizeof(uint2) + sizeof(unsigned short)), s, d, pbox, tcount, tlist, bx, tiles);
         if (ev_start) (void)hipEventRecord(ev_start, s);
         const dim3 tgrid((unsigned)d.B, (unsigned)tiles, (unsigned)tiles);
-        for (int rep = 0; rep < repeats; ++rep)
-            hipLaunchKernelGGL(raster_forward_tiled_kernel, tgrid, dim3(kThreads), 0, s, tcount, tlist, srec, pbox, d.F,
-                               rgba_out, saved, d);
+        const long ntiles = (long)tiles * tiles * d.B;
+        for (int rep = 0; rep < repeats; ++rep) {
+            if (ntiles >= SV3D_TILED_TWO_BLOCKS_MIN_TILES)
+                hipLaunchKernelGGL(raster_forward_tiled_kernel<2>, tgrid, dim3(kThreads / 2), 0, s, tcount, tlist, srec,
+                                   pbox, d.F, rgba_out, saved, d);
+            else
+                hipLaunchKernelGGL(raster_forward_tiled_kernel<1>, tgrid, dim3(kThreads), 0, s, tcount, tlist, srec,
+                                   pbox, d.F, rgba_out, saved, d);
+        }
         if (ev_stop) (void)hipEventRecord(ev_stop, s);
         return launch_status();
     }
