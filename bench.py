@@ -233,14 +233,17 @@ class RasterCase:
 
 
 def configs_leg(device, ev):
-    """The larger configurations, forward + backward through the C ABI on 64 images each (one GPU's
-    share of the reference recipe at batch 4: 8 camera hypotheses x (4 + 4 mirrored) images):
-    surface RGB on the 5120-face mesh, eight part maps in one pass, Chamfer 16 x 8192^2."""
+    """The larger configurations, forward + backward through the C ABI: 64 images each (one GPU's
+    share of the reference recipe at batch 4: 8 camera hypotheses x (4 + 4 mirrored) images) of
+    surface RGB on the 5120-face mesh and of eight part maps in one pass; the headline's silhouette
+    workload at 64 and 512 images per launch; Chamfer 16 x 8192^2."""
     from sv3d import _lib as L, workmodel
     out = {}
-    for name, kw in (("hd_surface_rgb", dict(subdivide=4, mode="surface", tex_size=6)),
-                     ("part_maps_8_per_pass", dict(subdivide=3, mode="vertex8"))):
-        case = RasterCase(device, 64, 256, sigma=1e-5, gamma=1e-4, anti_aliasing=True, **kw)
+    for name, batch, kw in (("hd_surface_rgb", 64, dict(subdivide=4, mode="surface", tex_size=6, sigma=1e-5, anti_aliasing=True)),
+                            ("part_maps_8_per_pass", 64, dict(subdivide=3, mode="vertex8", sigma=1e-5, anti_aliasing=True)),
+                            ("silhouette_batch_64", 64, dict(subdivide=3, mode="none", sigma=1e-4, alpha_only=True)),
+                            ("silhouette_batch_512", 512, dict(subdivide=3, mode="none", sigma=1e-4, alpha_only=True))):
+        case = RasterCase(device, batch, 256, gamma=1e-4, **kw)
         for _ in range(5):
             case.step()
         torch.cuda.synchronize()
@@ -252,12 +255,14 @@ def configs_leg(device, ev):
         dt = (time.perf_counter() - t0) / n
         fwd_ms, bwd_ms, launches = case.kernel_times(ev, launches=20, per_batch=5)
         r = case.roofline(fwd_ms, bwd_ms, launches)
-        out[name] = {"workload": "%s fwd+bwd, 64 images, 256x256 (2x AA raster), %d faces, sigma=1e-5%s"
-                                 % ("surface-texture RGB (T=6)" if kw["mode"] == "surface" else
-                                    "eight per-vertex part maps in one pass", case.F,
-                                    "" if kw["mode"] == "surface" else " (x8 maps per image)"),
-                     "ms_per_step": 1e3 * dt, "images_per_s": 64 / dt, "fwd_kernel_ms": fwd_ms, "bwd_kernel_ms": bwd_ms,
+        what = {"surface": "surface-texture RGB (T=6)", "vertex8": "eight per-vertex part maps in one pass",
+                "none": "silhouette (the headline workload at a larger batch)"}[kw["mode"]]
+        out[name] = {"workload": "%s fwd+bwd, %d images, 256x256%s, %d faces, sigma=%g%s"
+                                 % (what, batch, " (2x AA raster)" if kw.get("anti_aliasing") else "", case.F, kw["sigma"],
+                                    " (x8 maps per image)" if kw["mode"] == "vertex8" else ""),
+                     "ms_per_step": 1e3 * dt, "images_per_s": batch / dt, "fwd_kernel_ms": fwd_ms, "bwd_kernel_ms": bwd_ms,
                      "dominant_kernel": r["kernel"], "frac": r["frac"], "tflops": r["achieved"],
+                     "fwd_frac": r["other_kernel"]["fwd_frac"], "bwd_frac": r["other_kernel"]["bwd_frac"],
                      "active_pairs_per_launch": r["active_pairs_per_launch"], "flop_per_pair": r["flop_per_pair"]}
         del case
         torch.cuda.empty_cache()

@@ -79,14 +79,30 @@ class SoftNeuralRenderer(torch.nn.Module):
             return self._rgba_fused(vertices, faces, cams, None, scale, shift, alpha_only=True)
         return self._rgba_fused(vertices, faces, cams, textures, scale, shift)[:, :3]
 
+    def _packed(self, r, scale, shift, mode, res, alpha_only):
+        """The operators' packed configuration for the rasterizer's current settings; packed again
+        only when a setting changed (the mutators above, or a caller editing the rasterizer)."""
+        from sv3d import ops
+        key = (r.image_size, r.anti_aliasing, mode, res, r.fill_back, alpha_only, tuple(r.background_color), r.near,
+               r.far, r.eps, r.sigma_val, r.dist_eps, r.gamma_val, self.offset_z, scale, shift, ops._backward_enumeration)
+        hit = self.__dict__.get('_packed_cfg')
+        if hit is None or hit[0] != key:
+            icfg, fcfg = ops.raster_config(r.image_size, r.anti_aliasing, mode, res, r.fill_back, alpha_only,
+                                           r.background_color, r.near, r.far, r.eps, r.sigma_val, r.dist_eps, r.gamma_val)
+            hit = (key, ops._mesh_cfg(self.offset_z, scale, shift), icfg, fcfg)
+            self.__dict__['_packed_cfg'] = hit
+        return hit[1], hit[2], hit[3]
+
     def _rgba_fused(self, vertices, faces, cams, textures, scale, shift, alpha_only=False):
         r = self.renderer.rasterizer
+        if textures is None:
+            from sv3d import _lib, ops
+            self.__dict__['mask_only'] = True
+            mesh_cfg, icfg, fcfg = self._packed(r, scale, shift, _lib.SV3D_TEX_NONE, 1, alpha_only)
+            return ops.render_packed(vertices, cams, faces, None, mesh_cfg, icfg, fcfg)
         kw = dict(offset_z=self.offset_z, scale=scale, shift=shift, anti_aliasing=r.anti_aliasing,
                   background_color=r.background_color, near=r.near, far=r.far, eps=r.eps,
                   sigma_val=r.sigma_val, dist_eps=r.dist_eps, gamma_val=r.gamma_val, fill_back=r.fill_back)
-        if textures is None:
-            self.mask_only = True
-            return sv3d.render(vertices, cams, faces, None, r.image_size, alpha_only=alpha_only, **kw)
         self.mask_only = False
         if self.part_seg:
             self.renderer.set_texture_mode('vertex')

@@ -153,7 +153,14 @@ def render(vertices, cams, faces, textures=None, image_size=256, *, offset_z=0.0
     mode, res = _texture_mode(textures, texture_type)
     icfg, fcfg = raster_config(image_size, anti_aliasing, mode, res, fill_back, alpha_only, background_color,
                                near, far, eps, sigma_val, dist_eps, gamma_val)
-    rgba = _ops.render(vertices, cams, _faces_i32(faces), textures, _mesh_cfg(offset_z, scale, shift), icfg, fcfg)[0]
+    return render_packed(vertices, cams, faces, textures, _mesh_cfg(offset_z, scale, shift), icfg, fcfg)
+
+
+def render_packed(vertices, cams, faces, textures, mesh_cfg, icfg, fcfg):
+    """`render` with the configuration already packed (`raster_config`, `_mesh_cfg`): callers that
+    render with fixed settings pack them once instead of on every call."""
+    rgba = _ops.render(vertices, cams, _faces_i32(faces), textures, mesh_cfg, icfg, fcfg)[0]
+    mode, alpha_only = icfg[2], icfg[5]
     if not alpha_only:
         return rgba
     # without textures the image IS the alpha plane: a view, whose backward is a view too (selecting

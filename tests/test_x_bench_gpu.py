@@ -49,7 +49,7 @@ def test_bench_prints_one_json_line_with_roofline_and_cpu_baseline():
     v = t["variants"]
     assert v["hd_mesh"]["dataset_images_per_s"] > 5 and v["batch64_one_hypothesis"]["dataset_images_per_s"] > 50
     c = j["configs"]
-    for name in ("hd_surface_rgb", "part_maps_8_per_pass"):
+    for name in ("hd_surface_rgb", "part_maps_8_per_pass", "silhouette_batch_64", "silhouette_batch_512"):
         assert c[name]["images_per_s"] > 1e3 and 0 < c[name]["frac"] < 1 and c[name]["dominant_kernel"].startswith("raster_")
         assert c[name]["fwd_kernel_ms"] + c[name]["bwd_kernel_ms"] <= 1.05 * c[name]["ms_per_step"]
     assert "5120 faces" in c["hd_surface_rgb"]["workload"]
