@@ -2047,14 +2047,14 @@ int raster_forward_impl(const sv3d_raster_params *p, const float *face_vertices,
     uint2 *gbox = pbox + nf;                        // [B][face_groups(F)], then the coarse bins
     const dim3 sgrid((d.F + kThreads - 1) / kThreads, d.B);
     const int tiles = (d.S + kTile - 1) / kTile;
-    const bool coarse = coarse_enabled(d);
-    // two waves per block while the grid is small enough that single waves set the kernel's span
-    const bool split = (long)tiles * tiles * d.B <= SV3D_SPLIT_MAX_TILES;      // measured: 12 and 16 images of 256^2 are faster unsplit
-    // group boxes are read by the large launches without coarse bins only
-    uint2 *gbox_setup = (!coarse && !(SV3D_DIRECT_BOXES && split)) ? gbox : nullptr;
     // per-tile lists: counts [B][tiles][tiles], then (16-byte aligned) the faces' oriented silhouette
     // records, then the tiles' lists of face ids
     const bool tiled = tiled_enabled(d);
+    const bool coarse = coarse_enabled(d) && !tiled;
+    // two waves per block while the grid is small enough that single waves set the kernel's span
+    const bool split = (long)tiles * tiles * d.B <= SV3D_SPLIT_MAX_TILES;      // measured: 12 and 16 images of 256^2 are faster unsplit
+    // group boxes are read by the large launches without coarse bins or per-tile lists only
+    uint2 *gbox_setup = (!coarse && !tiled && !(SV3D_DIRECT_BOXES && split)) ? gbox : nullptr;
     int *tcount = nullptr;
     float4 *srec = nullptr;
     unsigned short *tlist = nullptr;

@@ -218,3 +218,22 @@ def test_tiled_forward_on_a_raster_that_is_not_a_power_of_two():
     B = 16
     fv = camera_space_faces(verts, faces, B, seed=14)
     sampled_compare("tiled_mask_200", fv, None, 200, False, "none", 256, check_images=(0, 9, 15), sigma=3e-5)
+
+
+@pytest.mark.parametrize("mode,sub", [("surface", 3), ("vertex", 3), ("vertex8", 3), ("surface", 4)])
+def test_colour_modes_in_a_launch_of_five_images(mode, sub):
+    """The colour modes in a launch of 5120 tiles (5 images at the 512^2 raster): the size from which
+    the silhouette forward takes per-tile face lists.  The colour modes keep the per-tile binning
+    of the general kernel at every size (their depth softmax, with gamma = 1e-4, needs barycentrics
+    to 1e-7, which the tile-relative records of the list path do not give: measured 2.5 - 3 x the
+    gradient error, 1.4e-5 on the 5120-face mesh); this pins them at that size."""
+    verts, faces = load_mesh(sub)
+    B = 5
+    fv = camera_space_faces(verts, faces, B, seed=20 + sub)
+    if mode == "vertex8":
+        tex = torch.softmax(torch.randn(B, faces.shape[0], 3, 8, generator=torch.Generator().manual_seed(5)), -1)
+    else:
+        tex = _textures(mode, B, faces.shape[0], 6)
+    sampled_compare("b5_%s_sub%d_512aa" % (mode, sub), fv, tex, 256, True, mode, 160, check_images=(0, 2, 4),
+                    background=(0.1, 0.3, 0.5))
+
