@@ -79,6 +79,18 @@ constexpr int kTile = 16;         // tile side in raster pixels
 #ifndef SV3D_TILED_TWO_BLOCKS_MIN_TILES
 #define SV3D_TILED_TWO_BLOCKS_MIN_TILES 12288   // two blocks per wave from this many tiles per launch
 #endif
+#ifndef SV3D_TILED_FUSED_MAX_TILES
+#define SV3D_TILED_FUSED_MAX_TILES 4096             // at most this many tiles: setup and lists in one launch
+#endif
+#ifndef SV3D_TILED_HALVES_MAX_TILES
+#define SV3D_TILED_HALVES_MAX_TILES 2048            // ... and two waves per block in the forward
+#endif
+#ifndef SV3D_TILED_HALVES_MAX_TILES_DENSE
+#define SV3D_TILED_HALVES_MAX_TILES_DENSE 3072      // the same for meshes of at least four faces per tile
+#endif
+#ifndef SV3D_TILED_MAX_FACES_PER_TILE
+#define SV3D_TILED_MAX_FACES_PER_TILE 8             // faces of the mesh per tile of an image, at most
+#endif
 #ifndef SV3D_TILED_MIN_TILES
 #define SV3D_TILED_MIN_TILES 4096                   // launches above this many tiles take the lists
 #endif
@@ -374,25 +386,17 @@ __device__ inline float4 oriented_edge(float ax, float ay, float bx, float by, f
     return make_float4(ax, ay, len2 > 0.f ? c * (ex * inv_len) : c, c * (ey * inv_len));
 }
 
-__device__ inline void setup_face(const DevParams &P, int gid, float x0, float y0, float z0, float x1,
-                                  float y1, float z1, float x2, float y2, float z2, float zref,
-                                  float4 *__restrict__ rec, uint2 *__restrict__ pbox, int &col0, int &col1,
-                                  int &row0, int &row1, float4 *__restrict__ srec = nullptr)
+// Pixel box of a face from the xy of its corners: the pixels whose centre lies inside the cull box
+// (bounding box widened by the margin); an empty box (col0 > col1) for a face that shows nowhere.
+// `raw_det`: the face's doubled signed area, see setup_face.
+__device__ inline void face_box(const DevParams &P, float x0, float y0, float x1, float y1, float x2, float y2,
+                                float raw_det, int &col0, int &col1, int &row0, int &row1)
 {
-    const float e0x = x1 - x0, e0y = y1 - y0;
-    const float e1x = x2 - x1, e1y = y2 - y1;
-    const float e2x = x0 - x2, e2y = y0 - y2;
-    const float l0 = e0x * e0x + e0y * e0y, l1 = e1x * e1x + e1y * e1y, l2 = e2x * e2x + e2y * e2y;
-    // both products rounded before the subtraction (no fma contraction), so that a face with two
-    // equal corners gets exactly 0
-    const float raw_det = cross_rounded(e0x, e0y, x2 - x0, y2 - y0);
-    const float det = raw_det > 0.f ? fmaxf(raw_det, 1e-10f) : fminf(raw_det, -1e-10f);
     const float bx0 = fminf(x0, fminf(x1, x2)) - P.margin, bx1 = fmaxf(x0, fmaxf(x1, x2)) + P.margin;
     const float by0 = fminf(y0, fminf(y1, y2)) - P.margin, by1 = fmaxf(y0, fmaxf(y1, y2)) + P.margin;
-
-    // pixel box: the pixels whose centre lies inside the cull box.  A pixel outside it is farther
-    // than the margin from the face, hence inactive, so the box bounds the work exactly; 0.01 pixel
-    // of slack covers the rounding of the conversion (below 1e-3 pixel up to the largest S).
+    // A pixel outside the cull box is farther than the margin from the face, hence inactive, so the
+    // box bounds the work exactly; 0.01 pixel of slack covers the rounding of the conversion (below
+    // 1e-3 pixel up to the largest S).
     const float fs = (float)P.S, hi = fs;
     const float cx0 = ceilf(fminf(fmaxf((fs * bx0 + fs - 1.f) * 0.5f, -2.f), hi) - 0.01f);
     const float cx1 = floorf(fminf(fmaxf((fs * bx1 + fs - 1.f) * 0.5f, -2.f), hi) + 0.01f);
@@ -411,8 +415,29 @@ __device__ inline void setup_face(const DevParams &P, int gid, float x0, float y
     if (!finite || no_area || col0 > col1 || row0 > row1) {
         col0 = 32767; col1 = -1; row0 = 32767; row1 = -1;
     }
-    const uint2 box = make_uint2((uint32_t)(col0 & 0xffff) | ((uint32_t)(col1 & 0xffff) << 16),
-                                 (uint32_t)(row0 & 0xffff) | ((uint32_t)(row1 & 0xffff) << 16));
+}
+
+__device__ inline uint2 pack_box(int col0, int col1, int row0, int row1)
+{
+    return make_uint2((uint32_t)(col0 & 0xffff) | ((uint32_t)(col1 & 0xffff) << 16),
+                      (uint32_t)(row0 & 0xffff) | ((uint32_t)(row1 & 0xffff) << 16));
+}
+
+__device__ inline void setup_face(const DevParams &P, int gid, float x0, float y0, float z0, float x1,
+                                  float y1, float z1, float x2, float y2, float z2, float zref,
+                                  float4 *__restrict__ rec, uint2 *__restrict__ pbox, int &col0, int &col1,
+                                  int &row0, int &row1, float4 *__restrict__ srec = nullptr)
+{
+    const float e0x = x1 - x0, e0y = y1 - y0;
+    const float e1x = x2 - x1, e1y = y2 - y1;
+    const float e2x = x0 - x2, e2y = y0 - y2;
+    const float l0 = e0x * e0x + e0y * e0y, l1 = e1x * e1x + e1y * e1y, l2 = e2x * e2x + e2y * e2y;
+    // both products rounded before the subtraction (no fma contraction), so that a face with two
+    // equal corners gets exactly 0
+    const float raw_det = cross_rounded(e0x, e0y, x2 - x0, y2 - y0);
+    const float det = raw_det > 0.f ? fmaxf(raw_det, 1e-10f) : fminf(raw_det, -1e-10f);
+    face_box(P, x0, y0, x1, y1, x2, y2, raw_det, col0, col1, row0, row1);
+    const uint2 box = pack_box(col0, col1, row0, row1);
     const float iz0 = 1.f / z0, iz1 = 1.f / z1, iz2 = 1.f / z2;
     float4 *r = rec + (size_t)gid * kRec4;
     r[0] = make_float4(x0, y0, x1, y1);
@@ -468,12 +493,10 @@ __device__ inline void store_group_box(const DevParams &P, int b, int f, bool va
                        (uint32_t)(r0 & 0xffff) | ((uint32_t)(r1 & 0xffff) << 16));
 }
 
-__global__ __launch_bounds__(kThreads) void raster_setup_kernel(
-    DevParams P, const float *__restrict__ fv, float4 *__restrict__ rec, uint2 *__restrict__ pbox,
-    uint2 *__restrict__ gbox,                   // gbox == nullptr: the forward will not read group boxes
-    float4 *__restrict__ srec)                  // oriented silhouette records, or nullptr
+__device__ inline void setup_from_face_vertices(
+    const DevParams &P, int b, int f, const float *__restrict__ fv, float4 *__restrict__ rec,
+    uint2 *__restrict__ pbox, uint2 *__restrict__ gbox, float4 *__restrict__ srec)
 {
-    const int b = blockIdx.y, f = blockIdx.x * kThreads + threadIdx.x;
     const bool valid = f < P.F;
     int col0 = 32767, col1 = -1, row0 = 32767, row1 = -1;
     if (valid) {
@@ -483,6 +506,14 @@ __global__ __launch_bounds__(kThreads) void raster_setup_kernel(
                    fv[(size_t)b * P.F * 9 + 2], rec, pbox, col0, col1, row0, row1, srec);
     }
     if (gbox) store_group_box(P, b, f, valid, col0, col1, row0, row1, gbox);
+}
+
+__global__ __launch_bounds__(kThreads) void raster_setup_kernel(
+    DevParams P, const float *__restrict__ fv, float4 *__restrict__ rec, uint2 *__restrict__ pbox,
+    uint2 *__restrict__ gbox,                   // gbox == nullptr: the forward will not read group boxes
+    float4 *__restrict__ srec)                  // oriented silhouette records, or nullptr
+{
+    setup_from_face_vertices(P, blockIdx.y, blockIdx.x * kThreads + threadIdx.x, fv, rec, pbox, gbox, srec);
 }
 
 // Setup straight from the object-space mesh: each thread projects its face's three vertices
@@ -496,11 +527,24 @@ struct MeshArgs {
     sv3d_dev::Affine a;
 };
 
-__global__ __launch_bounds__(kThreads) void raster_setup_mesh_kernel(
-    DevParams P, MeshArgs m, float *__restrict__ fv_out, float4 *__restrict__ rec,
+// The three projected corners of face f of image b (x, y, z each).
+__device__ inline void project_face(const MeshArgs &m, int F, int b, int f, float *__restrict__ o)
+{
+    const int32_t *fb = m.faces + (m.faces_batch > 1 ? (size_t)b * F * 3 : 0);
+    const sv3d_dev::Camera c = sv3d_dev::load_camera(m.cams + (size_t)b * 7, m.offset_z);
+    const float *vb = m.vertices + (size_t)b * m.V * 3;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int v = min(max(fb[f * 3 + k], 0), m.V - 1);
+        sv3d_dev::camera_project(c, m.a, vb[v * 3], vb[v * 3 + 1], vb[v * 3 + 2], o[3 * k], o[3 * k + 1],
+                                 o[3 * k + 2]);
+    }
+}
+
+__device__ inline void setup_from_mesh(
+    const DevParams &P, const MeshArgs &m, int b, int f, float *__restrict__ fv_out, float4 *__restrict__ rec,
     uint2 *__restrict__ pbox, uint2 *__restrict__ gbox, float4 *__restrict__ srec)
 {
-    const int b = blockIdx.y, f = blockIdx.x * kThreads + threadIdx.x;
     const bool valid = f < P.F;
     int col0 = 32767, col1 = -1, row0 = 32767, row1 = -1;
     if (valid) {
@@ -509,12 +553,7 @@ __global__ __launch_bounds__(kThreads) void raster_setup_mesh_kernel(
     const sv3d_dev::Camera c = sv3d_dev::load_camera(m.cams + (size_t)b * 7, m.offset_z);
     const float *vb = m.vertices + (size_t)b * m.V * 3;
     float o[9];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        const int v = min(max(fb[f * 3 + k], 0), m.V - 1);
-        sv3d_dev::camera_project(c, m.a, vb[v * 3], vb[v * 3 + 1], vb[v * 3 + 2], o[3 * k], o[3 * k + 1],
-                                 o[3 * k + 2]);
-    }
+    project_face(m, P.F, b, f, o);
     const int v00 = min(max(fb[0], 0), m.V - 1);
     float rx, ry, zref;
     sv3d_dev::camera_project(c, m.a, vb[v00 * 3], vb[v00 * 3 + 1], vb[v00 * 3 + 2], rx, ry, zref);
@@ -526,6 +565,13 @@ __global__ __launch_bounds__(kThreads) void raster_setup_mesh_kernel(
                row0, row1, srec);
     }
     if (gbox) store_group_box(P, b, f, valid, col0, col1, row0, row1, gbox);
+}
+
+__global__ __launch_bounds__(kThreads) void raster_setup_mesh_kernel(
+    DevParams P, MeshArgs m, float *__restrict__ fv_out, float4 *__restrict__ rec,
+    uint2 *__restrict__ pbox, uint2 *__restrict__ gbox, float4 *__restrict__ srec)
+{
+    setup_from_mesh(P, m, blockIdx.y, blockIdx.x * kThreads + threadIdx.x, fv_out, rec, pbox, gbox, srec);
 }
 
 __device__ inline void unpack_box(uint2 b, int &col0, int &col1, int &row0, int &row1)
@@ -1058,10 +1104,12 @@ __attribute__((amdgpu_waves_per_eu(MODE == SV3D_TEX_VERTEX8 ? 7 : 8))) void rast
 // For large launches the per-tile work of the forward that is not fragment arithmetic -- every tile
 // testing the boxes of its image's faces, numbering its hits, copying their 128-byte records and
 // testing each against its four blocks -- is nearly half of the kernel's instructions.  Here a
-// kernel of its own makes, per tile, the ordered list of the faces whose pixel box touches it, and
-// stores for each a compact record RELATIVE TO THE TILE'S CENTRE that the fragment loop can use
-// as it is.  One workgroup per (image, bin of 4x4 tiles): the bin's faces first (ordered
-// compaction over the image's pixel boxes, into LDS), then each of the bin's tiles against those.
+// kernel of its own makes, per tile, the ordered list of the faces whose pixel box touches it
+// (16-bit ids: lists of whole records cost more in memory traffic than they saved), and the
+// forward builds for each listed face a compact record RELATIVE TO THE TILE'S CENTRE, in LDS,
+// that the fragment loop can use as it is.  One workgroup per (image, bin of 4x4 tiles): the
+// bin's faces first (ordered compaction over the image's pixel boxes, into LDS), then each of
+// the bin's tiles against those.
 //
 // Tile-relative record (16 floats).  With c = sqrt(log2(e) / sigma), for each edge k taken from A
 // to B so that the face's inside is on its left (the two are swapped for faces of the other
@@ -1083,25 +1131,28 @@ constexpr int kTRecPad4 = 5;                    // LDS stride (80 B): lane-strid
 
 constexpr int kListThreads = 1024;              // sixteen waves: one per tile of the bin in the second phase
 
-__global__ __launch_bounds__(kListThreads) void raster_tile_lists_kernel(
-    DevParams P, const uint2 *__restrict__ pbox, int *__restrict__ tcount, unsigned short *__restrict__ tlist,
-    int bins_x, int tiles_x)
+// The lists of one (image, bin) by one workgroup.  stage(f0): called by all threads before the
+// faces f0 .. f0 + 1023 are looked at (it may synchronise the workgroup); box_of(f): the pixel box of
+// face f of the image (or a box that contains it: the forward drops a listed face whose own box
+// misses its tile).  `s_list`: LDS for F boxes and F 16-bit ids.
+template <class Stage, class BoxOf>
+__device__ inline void tile_lists_of_bin(const DevParams &P, int b, int bin, uint2 *s_list, Stage stage, BoxOf box_of,
+                                         int *__restrict__ tcount, unsigned short *__restrict__ tlist, int bins_x,
+                                         int tiles_x)
 {
-    extern __shared__ uint2 s_dyn_list[];       // per face of the bin: its pixel box, then the ids (16 bits each)
     __shared__ int s_cnt[kListThreads / 64];
-    uint2 *s_box = s_dyn_list;
-    unsigned short *s_id = reinterpret_cast<unsigned short *>(s_dyn_list + P.F);
-    const int b = blockIdx.y, bin = blockIdx.x;
+    uint2 *s_box = s_list;
+    unsigned short *s_id = reinterpret_cast<unsigned short *>(s_list + P.F);
     const int by = bin / bins_x, bx = bin - by * bins_x;
     const int c0 = bx * kBinPix, c1 = c0 + kBinPix - 1, r0 = by * kBinPix, r1 = r0 + kBinPix - 1;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     constexpr int NW = kListThreads / 64;
     const unsigned long long lane_lt = (1ull << lane) - 1ull;
-    const uint2 *pb = pbox + (size_t)b * P.F;
     int base = 0;                               // hits so far (uniform over the workgroup)
     for (int f0 = 0; f0 < P.F; f0 += kListThreads) {
+        stage(f0);
         const int f = f0 + threadIdx.x;
-        const uint2 box = f < P.F ? pb[f] : make_uint2(0xffff7fffu, 0xffff7fffu);
+        const uint2 box = f < P.F ? box_of(f) : make_uint2(0xffff7fffu, 0xffff7fffu);
         int a0, a1, b0, b1;
         unpack_box(box, a0, a1, b0, b1);
         const unsigned long long mask = __ballot(!(a1 < c0 || a0 > c1 || b1 < r0 || b0 > r1));
@@ -1144,9 +1195,77 @@ __global__ __launch_bounds__(kListThreads) void raster_tile_lists_kernel(
     if (lane == 0) tcount[tile] = n;
 }
 
+extern __shared__ uint2 s_dyn_list[];           // the list kernels' dynamic LDS
+
+__global__ __launch_bounds__(kListThreads) void raster_tile_lists_kernel(
+    DevParams P, const uint2 *__restrict__ pbox, int *__restrict__ tcount, unsigned short *__restrict__ tlist,
+    int bins_x, int tiles_x)
+{
+    const uint2 *pb = pbox + (size_t)blockIdx.y * P.F;
+    tile_lists_of_bin(P, blockIdx.y, blockIdx.x, s_dyn_list, [](int) {}, [&](int f) { return pb[f]; }, tcount, tlist,
+                      bins_x, tiles_x);
+}
+
+// Setup and lists in one launch, for launches small enough to be bound by the chain of their
+// launches rather than by their work.  The first workgroups of an image do the setup of 256 faces
+// each (a quarter of their threads: spread over many CUs, as the setup kernel's are), the `nbins`
+// behind them build the lists of one bin each -- they work the faces' pixel boxes out of the
+// corners themselves, every one of them for all the image's faces, instead of waiting for another
+// kernel to store them.  The corners come through LDS: a face's nine floats lie 36 bytes apart, and
+// read per face they would cost sixteen waves nine times eighteen cache lines each; read as they
+// lie they are two lines per instruction, and the next 1024 faces are under way while these are
+// looked at.  A box worked out twice could come out a pixel apart if the compiler contracted the
+// two copies of the arithmetic differently, so the list builders widen theirs by one pixel and the
+// forward tests the stored box again.
+constexpr int kStageFloats = kListThreads * 9;
+__host__ __device__ inline size_t lists_lds_bytes(int F) { return ((size_t)F * 10 + 15) & ~(size_t)15; }
+
+__global__ __launch_bounds__(kListThreads) void raster_setup_lists_kernel(
+    DevParams P, const float *__restrict__ fv, float4 *__restrict__ rec, uint2 *__restrict__ pbox,
+    float4 *__restrict__ srec, int *__restrict__ tcount, unsigned short *__restrict__ tlist, int bins_x,
+    int tiles_x, int setup_wgs)
+{
+    const int b = blockIdx.y;
+    if ((int)blockIdx.x < setup_wgs) {          // uniform over the workgroup
+        if (threadIdx.x < kThreads)
+            setup_from_face_vertices(P, b, (int)blockIdx.x * kThreads + (int)threadIdx.x, fv, rec, pbox, nullptr, srec);
+        return;
+    }
+    float *s_fv = reinterpret_cast<float *>(reinterpret_cast<char *>(s_dyn_list) + lists_lds_bytes(P.F));
+    const float *src = fv + (size_t)b * P.F * 9;
+    float nxt[9];
+    auto fetch = [&](int f0) {
+        const int n9 = min(kListThreads, P.F - f0) * 9;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            const int i = k * kListThreads + (int)threadIdx.x;
+            nxt[k] = i < n9 ? src[(size_t)f0 * 9 + i] : 0.f;
+        }
+    };
+    fetch(0);
+    auto stage = [&](int f0) {                  // the loop's closing barrier has freed s_fv
+#pragma unroll
+        for (int k = 0; k < 9; ++k) s_fv[k * kListThreads + threadIdx.x] = nxt[k];
+        if (f0 + kListThreads < P.F) fetch(f0 + kListThreads);
+        __syncthreads();
+    };
+    auto box_of = [&](int f) {
+        const float *v = s_fv + (f & (kListThreads - 1)) * 9;       // stride 9 words: no bank conflicts
+        const float x0 = v[0], y0 = v[1], x1 = v[3], y1 = v[4], x2 = v[6], y2 = v[7];
+        const float raw_det = cross_rounded(x1 - x0, y1 - y0, x2 - x0, y2 - y0);
+        int col0, col1, row0, row1;
+        face_box(P, x0, y0, x1, y1, x2, y2, raw_det, col0, col1, row0, row1);
+        if (col0 <= col1) { col0 -= 1; col1 += 1; row0 -= 1; row1 += 1; }
+        return pack_box(col0, col1, row0, row1);
+    };
+    tile_lists_of_bin(P, b, (int)blockIdx.x - setup_wgs, s_dyn_list, stage, box_of, tcount, tlist, bins_x, tiles_x);
+}
+
 // Tile-relative record of a face from its oriented silhouette record (e_k = Ax, Ay, Sx, Sy; the end
 // of edge k is the start of edge k+1) and pixel box.  (cx_num, cy_num): numerators over S of the
 // tile centre, which lies between pixel columns tc0+7 / tc0+8 and rows tr0+7 / tr0+8.
+constexpr unsigned kNoFace = 1u << 16;         // box field of a record slot without a face
+
 __device__ inline void make_tile_record(const float4 e0, const float4 e1, const float4 e2, uint2 box, int tc0, int tr0,
                                         float cx_num, float cy_num, float fS, float inv_S, float4 *__restrict__ o)
 {
@@ -1156,7 +1275,10 @@ __device__ inline void make_tile_record(const float4 e0, const float4 e1, const 
     const float d2x = fmaf(-e2.x, fS, cx_num) * inv_S, d2y = fmaf(-e2.y, fS, cy_num) * inv_S;
     int a0, a1, b0, b1;
     unpack_box(box, a0, a1, b0, b1);
-    const unsigned bits = (unsigned)min(max(a0 - tc0, 0), 15) | ((unsigned)min(max(a1 - tc0, 0), 15) << 4) |
+    // (a list may name a face whose box misses the tile by a pixel: see raster_setup_lists_kernel)
+    const bool misses = a1 < tc0 || a0 > tc0 + kTile - 1 || b1 < tr0 || b0 > tr0 + kTile - 1;
+    const unsigned bits = misses ? kNoFace :
+                          (unsigned)min(max(a0 - tc0, 0), 15) | ((unsigned)min(max(a1 - tc0, 0), 15) << 4) |
                           ((unsigned)min(max(b0 - tr0, 0), 15) << 8) | ((unsigned)min(max(b1 - tr0, 0), 15) << 12);
     // per edge: Sx, Sy, S0 = S.(centre - A), S1 = S.(centre - B), H0 = n.(centre - A), n = (-Sy, Sx)
     o[0] = make_float4(e0.z, e0.w, fmaf(e0.z, d0x, e0.w * d0y), fmaf(e0.z, d1x, e0.w * d1y));
@@ -1171,6 +1293,8 @@ __device__ inline void make_tile_record(const float4 e0, const float4 e1, const 
 // tile-relative records in LDS (one thread per face: ids, then the faces' records -- two trips to
 // memory -- and one barrier), and every wave tests the list against its 8x8 blocks lane-parallel
 // and walks its hits.
+// HALVES = 2 (NB = 1 only; the smallest launches, bound by their longest waves): eight waves, two per
+// block, which take the block's hits in turn and multiply their products together through LDS.
 // NB = 1: four waves, one block each.  NB = 2 (the largest launches): two waves, rows 0-7 and 8-15,
 // each wave's lanes holding one pixel of the left and one of the right block; a visit's record is
 // then read from LDS once for both blocks.  The four broadcast ds_read_b128 of a visit take 16
@@ -1193,19 +1317,25 @@ __device__ inline float tile_visit(const float4 r0, const float4 r1, const float
     return rcp(1.f + ex2(inside ? dd : -dd));
 }
 
-template <int NB>
-__global__ __launch_bounds__(kThreads / NB) void raster_forward_tiled_kernel(
+template <int NB, int HALVES>
+__global__ __launch_bounds__(kThreads / NB * HALVES) void raster_forward_tiled_kernel(
     const int *__restrict__ tcount, const unsigned short *__restrict__ tlist, const float4 *__restrict__ srec,
     const uint2 *__restrict__ pbox, int num_faces, float *__restrict__ rgba, float *__restrict__ saved, DevParams P)
 {
+    static_assert(HALVES == 1 || NB == 1, "two waves per block: one block per wave");
     __shared__ float4 s_trec[kTileCap * kTRecPad4];
+    __shared__ float s_half[HALVES == 2 ? kThreads : 1];
     const int tiles_x = (P.S + kTile - 1) / kTile;
     const int b = blockIdx.x;
     const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wave_id = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // neighbouring waves sit on different SIMDs: a block's two halves are waves 2k and 2k + 1
+    const int wave = HALVES == 2 ? wave_id >> 1 : wave_id, part = HALVES == 2 ? wave_id & 1 : 0;
     int tile_x, tile_y;
-    tile_position(blockIdx.y, blockIdx.z, tiles_x, false, tile_x, tile_y);
+    tile_position(blockIdx.y, blockIdx.z, tiles_x, SV3D_SPIRAL && HALVES == 2, tile_x, tile_y);
     const size_t tile = ((size_t)b * tiles_x + tile_y) * tiles_x + tile_x;
+    // the list's ids are requested alongside its length, not behind it
+    const int my_id = (int)threadIdx.x < kTileCap ? (int)tlist[tile * kTileCap + threadIdx.x] : 0;
     const int n_list = tcount[tile];
     const int S = P.S, F = num_faces;
     const int tile_c0 = tile_x * kTile, tile_r0 = tile_y * kTile;
@@ -1224,7 +1354,8 @@ __global__ __launch_bounds__(kThreads / NB) void raster_forward_tiled_kernel(
         const float bcy = br0 ? -8.f * P.inv_S : 8.f * P.inv_S, bcx = 8.f * P.inv_S;
         const float bh = 7.f * P.inv_S;
         const float cx_num = (float)(2 * tile_c0 + kTile - S), cy_num = (float)(S - kTile - 2 * tile_r0);
-        constexpr unsigned kNoFace = 1u << 16;                          // record slot without a face
+        const unsigned long long lane_lt = (1ull << lane) - 1ull;
+        int hits_seen = 0;                                              // hits of this block so far (wave-uniform)
 
         auto process_window = [&](int nw, bool last) {
             __syncthreads();
@@ -1252,7 +1383,13 @@ __global__ __launch_bounds__(kThreads / NB) void raster_forward_tiled_kernel(
                         hit0 = rows && (bc0 ? fc1 >= 8 && g >= -P.visit_r : fc0 <= 7 && l >= -P.visit_r);
                     }
                 }
-                const unsigned long long mask0 = __ballot(hit0), mask1 = __ballot(hit1);
+                unsigned long long mask0 = __ballot(hit0);
+                const unsigned long long mask1 = __ballot(hit1);
+                if (HALVES == 2) {              // the block's hits alternate between its two waves
+                    const bool mine = hit0 && (((hits_seen + __popcll(mask0 & lane_lt)) & 1) == part);
+                    hits_seen += __popcll(mask0);
+                    mask0 = __ballot(mine);
+                }
                 unsigned long long mask = mask0 | mask1;
                 while (mask) {
                     const int bit = __builtin_ctzll(mask);
@@ -1268,7 +1405,7 @@ __global__ __launch_bounds__(kThreads / NB) void raster_forward_tiled_kernel(
 
         if (n_list <= kTileCap) {
             if ((int)threadIdx.x < n_list) {    // one thread per face of the list builds its record in LDS
-                const size_t f = (size_t)b * F + tlist[tile * kTileCap + threadIdx.x];
+                const size_t f = (size_t)b * F + my_id;
                 const float4 *q = srec + f * 3;
                 make_tile_record(q[0], q[1], q[2], pbox[f], tile_c0, tile_r0, cx_num, cy_num, (float)S, P.inv_S,
                                  &s_trec[threadIdx.x * kTRecPad4]);
@@ -1296,6 +1433,14 @@ __global__ __launch_bounds__(kThreads / NB) void raster_forward_tiled_kernel(
                 process_window(nw, f0 + kTileCap >= F);
             }
         }
+        if (HALVES == 2) {                      // n_list is uniform over the workgroup: every wave is here
+            if (part == 1) s_half[wave * 64 + lane] = A0;
+            __syncthreads();
+            if (part == 1) return;
+            A0 *= s_half[wave * 64 + lane];
+        }
+    } else if (HALVES == 2 && part == 1) {
+        return;
     }
     const bool only_alpha = P.alpha_only;
     const int planes = only_alpha ? 1 : 4;
@@ -1983,11 +2128,27 @@ inline size_t coarse_bytes(const DevParams &d)
 
 // Per-tile lists: large silhouette launches whose tile, scaled by sqrt(log2(e)/sigma), is small enough
 // for the tile-relative evaluation to stay within the rounding the absolute one has.
+inline long launch_tiles(const DevParams &d)
+{
+    const long tiles = (d.S + kTile - 1) / kTile;
+    return tiles * tiles * d.B;
+}
+// small launches: setup and lists in one kernel, two waves per block in the forward
+inline bool tiled_fused(const DevParams &d) { return launch_tiles(d) <= SV3D_TILED_FUSED_MAX_TILES; }
+// Lists hold 128 faces; a tile with more goes through all of the image's faces instead, so a mesh
+// with many faces per tile (a coarse raster) keeps the binning forward.
 inline bool tiled_enabled(const DevParams &d)
 {
     const long tiles = (d.S + kTile - 1) / kTile;
-    return SV3D_TILED && d.mode == SV3D_TEX_NONE && d.alpha_fast && tiles * tiles * d.B > SV3D_TILED_MIN_TILES &&
-           d.F <= 6000 && d.c_scale * (float)kTile * d.inv_S <= 64.f;
+    return SV3D_TILED && d.mode == SV3D_TEX_NONE && d.alpha_fast &&
+           (launch_tiles(d) > SV3D_TILED_MIN_TILES || tiled_fused(d)) &&
+           d.F <= 6000 && (long)d.F <= SV3D_TILED_MAX_FACES_PER_TILE * tiles * tiles &&
+           d.c_scale * (float)kTile * d.inv_S <= 64.f;
+}
+inline bool tiled_halves(const DevParams &d)
+{
+    const long tiles = (d.S + kTile - 1) / kTile, n = launch_tiles(d);
+    return n <= SV3D_TILED_HALVES_MAX_TILES || (n <= SV3D_TILED_HALVES_MAX_TILES_DENSE && d.F >= 4 * tiles * tiles);
 }
 inline size_t tiled_bytes(const DevParams &d)
 {
@@ -2049,7 +2210,10 @@ int raster_forward_impl(const sv3d_raster_params *p, const float *face_vertices,
     const int tiles = (d.S + kTile - 1) / kTile;
     // per-tile lists: counts [B][tiles][tiles], then (16-byte aligned) the faces' oriented silhouette
     // records, then the tiles' lists of face ids
-    const bool tiled = tiled_enabled(d);
+    // (small launches from face_vertices only: a list builder would have to project the mesh's
+    // vertices once more per bin, and such calls come through the operators, bound by the host)
+    const bool fused = tiled_enabled(d) && tiled_fused(d) && !mesh;
+    const bool tiled = tiled_enabled(d) && (fused || launch_tiles(d) > SV3D_TILED_MIN_TILES);
     const bool coarse = coarse_enabled(d) && !tiled;
     // two waves per block while the grid is small enough that single waves set the kernel's span
     const bool split = (long)tiles * tiles * d.B <= SV3D_SPLIT_MAX_TILES;      // measured: 12 and 16 images of 256^2 are faster unsplit
@@ -2065,11 +2229,19 @@ int raster_forward_impl(const sv3d_raster_params *p, const float *face_vertices,
         srec = reinterpret_cast<float4 *>((reinterpret_cast<uintptr_t>(tbase + nt * sizeof(int)) + 15) & ~(uintptr_t)15);
         tlist = reinterpret_cast<unsigned short *>(srec + (size_t)d.B * d.F * 3);
     }
+    MeshArgs m = {};
     if (mesh) {
-        MeshArgs m;
         m.vertices = mesh->vertices; m.cams = mesh->cams; m.faces = mesh->faces;
         m.V = mesh->num_vertices; m.faces_batch = mesh->faces_batch; m.offset_z = mesh->offset_z;
         m.a = {mesh->scale[0], mesh->scale[1], mesh->scale[2], mesh->shift[0], mesh->shift[1], mesh->shift[2]};
+    }
+    if (fused) {
+        const int bx = coarse_bins_x(d), nbins = bx * bx, setup_wgs = (d.F + kThreads - 1) / kThreads;
+        const dim3 fgrid((unsigned)(setup_wgs + nbins), (unsigned)d.B);
+        hipLaunchKernelGGL(raster_setup_lists_kernel, fgrid, dim3(kListThreads),
+                           lists_lds_bytes(d.F) + kStageFloats * sizeof(float), s, d, face_vertices, rec, pbox, srec,
+                           tcount, tlist, bx, tiles, setup_wgs);
+    } else if (mesh) {
         hipLaunchKernelGGL(raster_setup_mesh_kernel, sgrid, dim3(kThreads), 0, s, d, m,
                            const_cast<float *>(face_vertices), rec, pbox, gbox_setup, srec);
     } else {
@@ -2087,18 +2259,22 @@ int raster_forward_impl(const sv3d_raster_params *p, const float *face_vertices,
     }
     if (tiled) {
         const int bx = coarse_bins_x(d);
-        hipLaunchKernelGGL(raster_tile_lists_kernel, dim3((unsigned)(bx * bx), (unsigned)d.B), dim3(kListThreads),
-                           (size_t)d.F * (sizeof(uint2) + sizeof(unsigned short)), s, d, pbox, tcount, tlist, bx, tiles);
+        if (!fused)
+            hipLaunchKernelGGL(raster_tile_lists_kernel, dim3((unsigned)(bx * bx), (unsigned)d.B), dim3(kListThreads),
+                               lists_lds_bytes(d.F), s, d, pbox, tcount, tlist, bx, tiles);
         if (ev_start) (void)hipEventRecord(ev_start, s);
         const dim3 tgrid((unsigned)d.B, (unsigned)tiles, (unsigned)tiles);
         const long ntiles = (long)tiles * tiles * d.B;
         for (int rep = 0; rep < repeats; ++rep) {
             if (ntiles >= SV3D_TILED_TWO_BLOCKS_MIN_TILES)
-                hipLaunchKernelGGL(raster_forward_tiled_kernel<2>, tgrid, dim3(kThreads / 2), 0, s, tcount, tlist, srec,
-                                   pbox, d.F, rgba_out, saved, d);
+                hipLaunchKernelGGL((raster_forward_tiled_kernel<2, 1>), tgrid, dim3(kThreads / 2), 0, s, tcount, tlist,
+                                   srec, pbox, d.F, rgba_out, saved, d);
+            else if (tiled_halves(d))
+                hipLaunchKernelGGL((raster_forward_tiled_kernel<1, 2>), tgrid, dim3(kThreads * 2), 0, s, tcount, tlist,
+                                   srec, pbox, d.F, rgba_out, saved, d);
             else
-                hipLaunchKernelGGL(raster_forward_tiled_kernel<1>, tgrid, dim3(kThreads), 0, s, tcount, tlist, srec,
-                                   pbox, d.F, rgba_out, saved, d);
+                hipLaunchKernelGGL((raster_forward_tiled_kernel<1, 1>), tgrid, dim3(kThreads), 0, s, tcount, tlist,
+                                   srec, pbox, d.F, rgba_out, saved, d);
         }
         if (ev_stop) (void)hipEventRecord(ev_stop, s);
         return launch_status();

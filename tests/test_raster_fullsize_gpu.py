@@ -15,6 +15,14 @@ same figures for the oracle's own upstream-style formulas evaluated densely in f
 inputs (what single precision costs with SoftRas's barycentric `t - w` algebra, before any kernel
 is involved): max-norm 4e-2 .. 6e-2, p999 of order 1.
 
+Sliver faces are left out of the gradient comparison (and counted): a face whose three projected
+corners are collinear to fp32 -- longest edge squared above 1e5 times its doubled area, so that
+rounding the corner differences alone moves the area by a per cent or more -- has coincident
+edges, and which of them is "nearest" to a pixel, hence which corners its distance gradient goes
+to, is decided by rounding in any precision.  The oracle freezes that choice as fp64 makes it.
+Such a face's gradient is a thousandth of the largest one; one in a random pose of the 1280-face
+sphere is enough to reach 1e-5 of the largest entry.
+
 Sizes follow the reference's defaults (softras.py:33-37: sigma 1e-5, gamma 1e-4, anti-aliasing;
 mesh_net.py:34 tex_size 6; utils/mesh.py:13-14 subdivide 3 / 4; main.py:56 part maps).
 """
@@ -79,6 +87,15 @@ def _raster_pixels(out_pix, img, aa):
     return torch.stack(sub, 1)
 
 
+def _sliver_faces(fv_b):
+    """[F] bool: faces whose projected corners are collinear to fp32 (see the module docstring)."""
+    p = fv_b[..., :2].double()
+    e = p[:, [1, 2, 0]] - p
+    longest2 = (e * e).sum(-1).max(-1).values
+    area2 = (e[:, 0, 0] * (p[:, 2, 1] - p[:, 0, 1]) - e[:, 0, 1] * (p[:, 2, 0] - p[:, 0, 0])).abs()
+    return longest2 > 1e5 * area2
+
+
 def sampled_compare(name, fv, tex, img, aa, mode, n_out, check_images=None, fp32_floor=False, **kw):
     """GPU forward + backward over the whole batch; oracle on `n_out` output pixels of every image
     in `check_images` (default: all).  Returns the worst errors."""
@@ -117,14 +134,17 @@ def sampled_compare(name, fv, tex, img, aa, mode, n_out, check_images=None, fp32
     gtex = t.grad.cpu() if t is not None else None
     assert torch.isfinite(got).all() and torch.isfinite(gfv).all()
 
-    worst = dict(img=0.0, grad_fv=0.0, grad_tex=0.0, p999_fv=0.0, p999_tex=0.0, unstable=0.0)
+    worst = dict(img=0.0, grad_fv=0.0, grad_tex=0.0, p999_fv=0.0, p999_tex=0.0, unstable=0.0, sliver_faces=0.0)
     for b, (out_pix, xb, tb, want, unstable, vals) in per_image.items():
         (want * vals.double()).sum().backward()
         keep = ~unstable
         e_img = float((got[b][:, out_pix].double() - want.detach())[:, keep].abs().max() / want.detach().abs().max())
         worst["img"] = max(worst["img"], e_img)
-        worst["grad_fv"] = max(worst["grad_fv"], rel_err(gfv[b], xb.grad))
-        worst["p999_fv"] = max(worst["p999_fv"], elementwise_rel_err(gfv[b], xb.grad))
+        sliver = _sliver_faces(fv[b])
+        worst["sliver_faces"] += float(sliver.sum())
+        err_fv = (gfv[b].double() - xb.grad).abs()[~sliver].max() / xb.grad.abs().max()
+        worst["grad_fv"] = max(worst["grad_fv"], float(err_fv))
+        worst["p999_fv"] = max(worst["p999_fv"], elementwise_rel_err(gfv[b][~sliver], xb.grad[~sliver]))
         worst["unstable"] = max(worst["unstable"], float(unstable.float().mean()))
         assert float(xb.grad.abs().max()) > 0
         if tb is not None:
@@ -141,7 +161,7 @@ def sampled_compare(name, fv, tex, img, aa, mode, n_out, check_images=None, fp32
         worst["fp32_upstream_grad_fv"] = rel_err(x32.grad, xb.grad)
         worst["fp32_upstream_p999_fv"] = elementwise_rel_err(x32.grad, xb.grad)
     _record(name, **worst)
-    assert worst["unstable"] < 2e-2, worst
+    assert worst["unstable"] < 2e-2 and worst["sliver_faces"] <= 2 * len(check), worst
     assert worst["img"] < TOL and worst["grad_fv"] < TOL and worst["grad_tex"] < TOL, worst
     assert worst["p999_fv"] < P999_TOL and worst["p999_tex"] < P999_TOL, worst
     return worst
@@ -197,18 +217,36 @@ def test_batch_40_launch_against_the_oracle(mode):
                     sigma=1e-4, gamma=1e-3)
 
 
-def test_tiled_forward_with_more_faces_in_a_tile_than_a_list_holds():
-    """Large silhouette launches take per-tile face lists of at most 128 faces; a tile with more
-    (here the 5120-face mesh drawn a fifth of the screen wide: several hundred faces per tile)
-    goes through all faces itself.  9 images x 256 tiles: above the size where the lists start."""
+@pytest.mark.parametrize("B", [2, 5])
+def test_tiled_forward_with_more_faces_in_a_tile_than_a_list_holds(B):
+    """Silhouette launches take per-tile face lists of at most 128 faces; a tile with more (here the
+    5120-face mesh drawn a fifth of the screen wide on a 512^2 raster: a few dozen tiles share all
+    its faces) goes through all faces itself.  Two images: the launch whose setup kernel also
+    builds the lists; five: lists from a kernel of their own."""
     verts, faces = load_mesh(4)
-    B = 9
     fv = camera_space_faces(verts, faces, B, seed=12)
-    fv[..., :2] *= 0.3                                      # x, y: a small object, dense in faces
+    fv[..., :2] *= 0.2                                      # x, y: a small object, dense in faces
     fv[..., 0] += 0.21
-    w = sampled_compare("tiled_overflow_hd_small_256", fv, None, 256, False, "none", 256, check_images=(0, 4, 8),
-                        sigma=1e-4)
+    w = sampled_compare("tiled_overflow_hd_small_512_b%d" % B, fv, None, 512, False, "none", 256,
+                        check_images=(0, B - 1), sigma=3e-5)
     assert w["img"] < TOL
+
+
+@pytest.mark.parametrize("B,img,aa,sub,sigma", [
+    (8, 256, False, 3, 1e-4),       # the benchmark configuration: 2048 tiles, two waves per block
+    (12, 256, False, 3, 1e-4),      # 3072 tiles of a mesh with five faces per tile: still two waves per block
+    (3, 256, True, 3, 1e-5),        # 3072 tiles, one wave per block
+    (4, 200, False, 3, 3e-5),       # partial tiles at the border, pixel centres fp32 cannot hold exactly
+    (1, 256, True, 4, 1e-5),        # 5120 faces: the list builders stage them 1024 at a time
+])
+def test_small_silhouette_launches_with_setup_and_lists_in_one_kernel(B, img, aa, sub, sigma):
+    """Launches of at most 4096 tiles that come with face_vertices: one kernel does the setup and
+    builds the per-tile lists (its list builders work the pixel boxes out for themselves, a pixel
+    wider than the stored ones), the forward takes the lists."""
+    verts, faces = load_mesh(sub)
+    fv = camera_space_faces(verts, faces, B, seed=30 + B)
+    sampled_compare("fused_lists_b%d_%d%s_sub%d" % (B, img, "aa" if aa else "", sub), fv, None, img, aa, "none",
+                    256, check_images=sorted({0, B // 2, B - 1}), sigma=sigma)
 
 
 def test_tiled_forward_on_a_raster_that_is_not_a_power_of_two():

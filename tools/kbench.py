@@ -34,9 +34,11 @@ CONFIGS = {
     "ref_mask_b8": (8, 256, True, 3, 1e-5, "none", 1),
     "ref_mask_b3": (3, 256, True, 3, 1e-5, "none", 1),
     "ref_mask_b2": (2, 256, True, 3, 1e-5, "none", 1),
+    "hd_mask_b2": (2, 256, True, 4, 1e-5, "none", 1),         # 5120 faces in a small launch
     "ref_rgb_b2": (2, 256, True, 3, 1e-5, "surface", 6),
     "s128_b32": (32, 128, False, 3, 1e-4, "none", 1),
     "s64_b64": (64, 64, False, 2, 1e-4, "none", 1),
+    "s128_b128": (128, 128, False, 3, 1e-4, "none", 1),     # many faces per tile in a large launch
     "ref_rgb_b3": (3, 256, True, 3, 1e-5, "surface", 6),
     "c2_rgb_b12": (12, 256, False, 3, 1e-4, "surface", 6),
     "ref_rgb_b8": (8, 256, True, 3, 1e-5, "surface", 6),
