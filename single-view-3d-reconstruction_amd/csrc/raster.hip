@@ -238,6 +238,7 @@ struct PairGeom {
     bool k0, k1, k2;              // which edge is nearest (first wins ties)
     bool inside, act;
     float D, omD;                 // sigmoid fragment and 1 - D
+    float D_any;                  // the fragment before the activity test (D where act, else arbitrary)
 };
 
 // A pixel centre as the kernels carry it.  (2c + 1 - S) / S is exact in fp32 when S is a power of
@@ -294,6 +295,7 @@ __device__ inline PairGeom pair_geom(const FaceRec &r, const Pixel &px, const De
     // exp(-x) with x = +-d2/sigma; D = 1/(1+exp(-x)); 1-D = exp(-x) D (no cancellation)
     const float e = ex2((g.inside ? g.d2 : -g.d2) * P.neg_l2e_over_sigma);
     const float D = rcp(1.f + e);
+    g.D_any = D;
     g.D = g.act ? D : 0.f;
     g.omD = g.act ? e * D : 1.f;
     return g;
@@ -1608,6 +1610,8 @@ __global__ __launch_bounds__(kThreads) void raster_backward_kernel(
     const float *saved_b = saved + (size_t)b * S * S * PP;
     const int H = aa_ == 2 ? S >> 1 : S;
     const float gscale = aa_ == 2 ? 0.25f : 1.f;
+    // d(+-d2 / sigma) / d(d2), doubled for d(d2) / d(foot - pixel)
+    const float dist_slope = (MODE == SV3D_TEX_NONE ? 2.f * gscale : 2.f) * P.inv_sigma;
     const size_t plane = (size_t)H * H;
     const bool only_alpha = MODE == SV3D_TEX_NONE && alpha_only_;
     // colour + alpha planes of image b, or its alpha plane alone
@@ -1672,6 +1676,9 @@ __global__ __launch_bounds__(kThreads) void raster_backward_kernel(
     constexpr int kStride = 64 * HALVES;        // pixel numbers between two steps of one wave
     const int rows_live = npix > 0 ? bh : 0;
     float adv_x = 0.f, adv_y = 0.f, rx_f = 0.f, ry_f = 0.f;
+    // without anti-aliasing the lane's pixel index is carried along with its position: a step adds
+    // one of two wave-uniform increments (with or without a row wrap)
+    int pix_run = 0, pix_adv = 0, pix_adv_wrap = 0;
     if (!SPANS) {
         const float inv_bw = bw > 0 ? rcp((float)bw) : 0.f;     // the fix-ups below absorb its last-bit error
         // kStride = adv_y * bw + adv_x, by the reciprocal and the same fix-ups as the lanes' start below
@@ -1685,6 +1692,9 @@ __global__ __launch_bounds__(kThreads) void raster_backward_kernel(
         rx_f = fmaf(-ry_f, bw_f, lane0);
         if (rx_f < 0.f) { ry_f -= 1.f; rx_f += bw_f; }
         if (rx_f >= bw_f) { ry_f += 1.f; rx_f -= bw_f; }
+        pix_run = (row0 + (int)ry_f) * S + col0 + (int)rx_f;
+        pix_adv = (int)adv_y * S + (int)adv_x;
+        pix_adv_wrap = pix_adv + S - bw;
     }
 
     // Raw per-pixel inputs: the forward's saved aggregates and the incoming gradient.  They are
@@ -1708,6 +1718,7 @@ __global__ __launch_bounds__(kThreads) void raster_backward_kernel(
     auto fetch = [&](int base) {                    // inputs of pixel number base + lane
         PixIn in;
         float cx, cy;
+        unsigned pix = 0, gpix = 0;
         if (SPANS) {
             const int pnum = base + lane;
             in.valid = pnum < span_total;
@@ -1749,14 +1760,22 @@ __global__ __launch_bounds__(kThreads) void raster_backward_kernel(
             cy = in.valid ? (float)(span_row0 + rowv) : 0.f;
         } else {
             in.valid = ry_f < bh_f;
-            cx = in.valid ? rx_f : 0.f;
-            cy = in.valid ? ry_f : 0.f;
+            // a lane past the box keeps its (finite) position: nothing of it is used but the pixel
+            // indices, which are made valid ones
+            cx = rx_f;
+            cy = ry_f;
+            pix = gpix = in.valid ? (unsigned)pix_run : 0u;
+            if (aa_ == 2) {                     // wave-uniform
+                const unsigned prow = (unsigned)(row0 + (int)cy), pcol = (unsigned)(col0 + (int)cx);
+                gpix = in.valid ? __umul24(prow >> 1, (unsigned)H) + (pcol >> 1) : 0u;
+            }
             // advance to the pixel kStride positions further
             rx_f += adv_x;
             ry_f += adv_y;
             const bool wrap = rx_f >= bw_f;
             rx_f -= wrap ? bw_f : 0.f;
             ry_f += wrap ? 1.f : 0.f;
+            pix_run += wrap ? pix_adv_wrap : pix_adv;
         }
         in.xp = fmaf(cx, step, xp0);
         in.yp = fmaf(-cy, step, yp0);
@@ -1766,10 +1785,12 @@ __global__ __launch_bounds__(kThreads) void raster_backward_kernel(
         } else {
             in.xl = in.yl = 0.f;
         }
-        const unsigned prow = (unsigned)(row0 + (int)cy), pcol = (unsigned)(col0 + (int)cx);
-        // rows, columns and sizes are at most 4096: 24-bit multiplies (one v_mad_u32_u24 each)
-        const unsigned pix = __umul24(prow, (unsigned)S) + pcol;
-        const unsigned gpix = aa_ == 2 ? __umul24(prow >> 1, (unsigned)H) + (pcol >> 1) : pix;
+        if (SPANS) {
+            const unsigned prow = (unsigned)(row0 + (int)cy), pcol = (unsigned)(col0 + (int)cx);
+            // rows, columns and sizes are at most 4096: 24-bit multiplies (one v_mad_u32_u24 each)
+            pix = __umul24(prow, (unsigned)S) + pcol;
+            gpix = aa_ == 2 ? __umul24(prow >> 1, (unsigned)H) + (pcol >> 1) : pix;
+        }
         in.ssum = in.m = 0.f;
 #pragma unroll
         for (int c = 0; c < NC; ++c) in.col[c] = in.gch[c] = 0.f;
@@ -1857,8 +1878,9 @@ __global__ __launch_bounds__(kThreads) void raster_backward_kernel(
         if (base + kStride < span_total) nxt = fetch(base + kStride);   // wave-uniform
         const float xp = in.xp, yp = in.yp;
         const bool valid = in.valid;
-        // fold the gradient with the aggregates: g_alpha A and g_k / ssum
-        const float P0 = in.A * (in.ga * gscale);
+        // fold the gradient with the aggregates: g_alpha A and g_k / ssum (silhouettes: the
+        // anti-aliasing scale rides on the constant of the distance's chain rule below)
+        const float P0 = MODE == SV3D_TEX_NONE ? in.A * in.ga : in.A * (in.ga * gscale);
         float G[NC];
         const float mfin = in.m;
         if (MODE != SV3D_TEX_NONE) {
@@ -1872,7 +1894,8 @@ __global__ __launch_bounds__(kThreads) void raster_backward_kernel(
         px.x = xp; px.y = yp; px.xl = in.xl; px.yl = in.yl;
         PairGeom g = pair_geom<LO>(r, px, P);
         const bool act = valid && g.act;
-        float gx = act ? P0 * g.D : 0.f;        // dL/dx, x = +-d2/sigma, through alpha
+        // dL/dx, x = +-d2/sigma, through alpha
+        float gx = act ? P0 * (MODE == SV3D_TEX_NONE ? g.D_any : g.D) : 0.f;
 
         if (MODE != SV3D_TEX_NONE) {
             const PairDepth d = pair_depth(r, g, P);
@@ -1956,7 +1979,7 @@ __global__ __launch_bounds__(kThreads) void raster_backward_kernel(
             }
         }
         // through the distance: d2 = |foot - pixel|^2, foot = (1-t) p_k + t p_{k+1}
-        const float gd = 2.f * gx * (g.inside ? P.inv_sigma : -P.inv_sigma);
+        const float gd = gx * (g.inside ? dist_slope : -dist_slope);
         const float cA = gd * (1.f - g.t), cB = gd * g.t;
         const float f0 = g.k0 ? cA : (g.k2 ? cB : 0.f);
         const float f1 = g.k1 ? cA : (g.k0 ? cB : 0.f);
