@@ -91,6 +91,9 @@ constexpr int kTile = 16;         // tile side in raster pixels
 #ifndef SV3D_TILED_MAX_FACES_PER_TILE
 #define SV3D_TILED_MAX_FACES_PER_TILE 8             // faces of the mesh per tile of an image, at most
 #endif
+#ifndef SV3D_BWD_UNROLL
+#define SV3D_BWD_UNROLL 1                           // silhouette backward: two steps per loop trip
+#endif
 #ifndef SV3D_TILED_MIN_TILES
 #define SV3D_TILED_MIN_TILES 4096                   // launches above this many tiles take the lists
 #endif
@@ -1131,70 +1134,99 @@ constexpr int kTileCap = 128;                   // records per tile slot
 
 constexpr int kTRecPad4 = 5;                    // LDS stride (80 B): lane-strided b128 reads are conflict free
 
-constexpr int kListThreads = 1024;              // sixteen waves: one per tile of the bin in the second phase
+constexpr int kListThreads = 256;               // the list kernel: four waves, each takes a row of the bin's tiles
+constexpr int kListFaces = 5;                   // ... and a thread five faces per pass (1280 per workgroup)
+constexpr int kFusedThreads = 1024;             // setup + lists in one kernel: sixteen waves, one per tile
 
-// The lists of one (image, bin) by one workgroup.  stage(f0): called by all threads before the
-// faces f0 .. f0 + 1023 are looked at (it may synchronise the workgroup); box_of(f): the pixel box of
-// face f of the image (or a box that contains it: the forward drops a listed face whose own box
-// misses its tile).  `s_list`: LDS for F boxes and F 16-bit ids.
-template <class Stage, class BoxOf>
+// The lists of one (image, bin) by one workgroup of NT threads.  Faces are taken NT * U at a time,
+// U per thread (thread t: faces f0 + u NT + t), all of a pass's boxes requested at once.
+// stage(f0): called by all threads before the faces f0 .. f0 + NT U - 1 are looked at (it may
+// synchronise the workgroup); box_of(f): the pixel box of face f of the image (or a box that
+// contains it: the forward drops a listed face whose own box misses its tile).  `s_list`: LDS for
+// F boxes and F 16-bit ids.  Second phase: a wave takes 16 / (NT / 64) of the bin's sixteen tiles
+// and tests each candidate against all of them.
+template <int NT, int U, class Stage, class BoxOf>
 __device__ inline void tile_lists_of_bin(const DevParams &P, int b, int bin, uint2 *s_list, Stage stage, BoxOf box_of,
                                          int *__restrict__ tcount, unsigned short *__restrict__ tlist, int bins_x,
                                          int tiles_x)
 {
-    __shared__ int s_cnt[kListThreads / 64];
+    constexpr int NW = NT / 64;
+    constexpr int K = kBinTiles * kBinTiles / NW;       // tiles per wave
+    static_assert(K >= 1 && K * NW == kBinTiles * kBinTiles && (K == 1 || K == kBinTiles), "a wave: one tile or one row");
+    __shared__ int s_cnt[U * NW];
     uint2 *s_box = s_list;
     unsigned short *s_id = reinterpret_cast<unsigned short *>(s_list + P.F);
     const int by = bin / bins_x, bx = bin - by * bins_x;
     const int c0 = bx * kBinPix, c1 = c0 + kBinPix - 1, r0 = by * kBinPix, r1 = r0 + kBinPix - 1;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    constexpr int NW = kListThreads / 64;
     const unsigned long long lane_lt = (1ull << lane) - 1ull;
     int base = 0;                               // hits so far (uniform over the workgroup)
-    for (int f0 = 0; f0 < P.F; f0 += kListThreads) {
+    for (int f0 = 0; f0 < P.F; f0 += NT * U) {
         stage(f0);
-        const int f = f0 + threadIdx.x;
-        const uint2 box = f < P.F ? box_of(f) : make_uint2(0xffff7fffu, 0xffff7fffu);
-        int a0, a1, b0, b1;
-        unpack_box(box, a0, a1, b0, b1);
-        const unsigned long long mask = __ballot(!(a1 < c0 || a0 > c1 || b1 < r0 || b0 > r1));
-        if (lane == 0) s_cnt[wave] = __popcll(mask);
-        __syncthreads();
-        int off = base, total = 0;
+        uint2 box[U];
+        unsigned long long mask[U];
 #pragma unroll
-        for (int w = 0; w < NW; ++w) {          // face order: wave, then lane
-            const int cw = s_cnt[w];
-            off += w < wave ? cw : 0;
-            total += cw;
+        for (int u = 0; u < U; ++u) {
+            const int f = f0 + u * NT + (int)threadIdx.x;
+            box[u] = f < P.F ? box_of(f) : make_uint2(0xffff7fffu, 0xffff7fffu);
         }
-        if ((mask >> lane) & 1ull) {
-            const int pos = off + __popcll(mask & lane_lt);
-            s_box[pos] = box;
-            s_id[pos] = (unsigned short)f;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            int a0, a1, b0, b1;
+            unpack_box(box[u], a0, a1, b0, b1);
+            mask[u] = __ballot(!(a1 < c0 || a0 > c1 || b1 < r0 || b0 > r1));
+            if (lane == 0) s_cnt[u * NW + wave] = __popcll(mask[u]);
         }
-        base += total;
+        __syncthreads();
+        int run = base;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {           // face order: pass slot u, wave, lane
+            int off = 0;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) {
+                const int cw = s_cnt[u * NW + w];
+                off = w == wave ? run : off;
+                run += cw;
+            }
+            if ((mask[u] >> lane) & 1ull) {
+                const int pos = off + __popcll(mask[u] & lane_lt);
+                s_box[pos] = box[u];
+                s_id[pos] = (unsigned short)(f0 + u * NT + (int)threadIdx.x);
+            }
+        }
+        base = run;
         __syncthreads();
     }
     const int nbin = base;
-    const int t = wave;                                             // one wave per tile of the bin
-    const int tx = bx * kBinTiles + (t & (kBinTiles - 1)), ty = by * kBinTiles + t / kBinTiles;
-    if (tx >= tiles_x || ty >= tiles_x) return;                     // whole wave; no barrier follows
-    const int tc0 = tx * kTile, tr0 = ty * kTile, tc1 = tc0 + kTile - 1, tr1 = tr0 + kTile - 1;
-    const size_t tile = ((size_t)b * tiles_x + ty) * tiles_x + tx;
-    unsigned short *slot = tlist + tile * kTileCap;
-    int n = 0;
+    // wave -> its tiles: K == 1: tile `wave` of the bin; K == 4: the four tiles of row `wave`
+    const int ty = by * kBinTiles + (K == 1 ? wave / kBinTiles : wave);
+    const int tx0 = bx * kBinTiles + (K == 1 ? (wave & (kBinTiles - 1)) : 0);
+    if (ty >= tiles_x || tx0 >= tiles_x) return;                    // whole wave; no barrier follows
+    const int tr0 = ty * kTile, tr1 = tr0 + kTile - 1;
+    int n[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) n[k] = 0;
+    const size_t tile0 = ((size_t)b * tiles_x + ty) * tiles_x + tx0;
     for (int j0 = 0; j0 < nbin; j0 += 64) {
         const int j = j0 + lane;
-        const uint2 box = j < nbin ? s_box[j] : make_uint2(0xffff7fffu, 0xffff7fffu);
+        const uint2 bxj = j < nbin ? s_box[j] : make_uint2(0xffff7fffu, 0xffff7fffu);
+        const unsigned short id = j < nbin ? s_id[j] : (unsigned short)0;
         int a0, a1, b0, b1;
-        unpack_box(box, a0, a1, b0, b1);
-        const bool hit = !(a1 < tc0 || a0 > tc1 || b1 < tr0 || b0 > tr1);
-        const unsigned long long mask = __ballot(hit);
-        const int pos = n + __popcll(mask & lane_lt);
-        if (hit && pos < kTileCap) slot[pos] = s_id[j];
-        n += __popcll(mask);
+        unpack_box(bxj, a0, a1, b0, b1);
+        const bool rows = !(b1 < tr0 || b0 > tr1);
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const int tc0 = (tx0 + k) * kTile, tc1 = tc0 + kTile - 1;
+            const bool hit = rows && !(a1 < tc0 || a0 > tc1);
+            const unsigned long long mask = __ballot(hit);
+            const int pos = n[k] + __popcll(mask & lane_lt);
+            if (hit && pos < kTileCap && tx0 + k < tiles_x) tlist[(tile0 + k) * kTileCap + pos] = id;
+            n[k] += __popcll(mask);
+        }
     }
-    if (lane == 0) tcount[tile] = n;
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+        if (lane == 0 && tx0 + k < tiles_x) tcount[tile0 + k] = n[k];
 }
 
 extern __shared__ uint2 s_dyn_list[];           // the list kernels' dynamic LDS
@@ -1204,8 +1236,8 @@ __global__ __launch_bounds__(kListThreads) void raster_tile_lists_kernel(
     int bins_x, int tiles_x)
 {
     const uint2 *pb = pbox + (size_t)blockIdx.y * P.F;
-    tile_lists_of_bin(P, blockIdx.y, blockIdx.x, s_dyn_list, [](int) {}, [&](int f) { return pb[f]; }, tcount, tlist,
-                      bins_x, tiles_x);
+    tile_lists_of_bin<kListThreads, kListFaces>(P, blockIdx.y, blockIdx.x, s_dyn_list, [](int) {},
+                                                [&](int f) { return pb[f]; }, tcount, tlist, bins_x, tiles_x);
 }
 
 // Setup and lists in one launch, for launches small enough to be bound by the chain of their
@@ -1219,10 +1251,10 @@ __global__ __launch_bounds__(kListThreads) void raster_tile_lists_kernel(
 // looked at.  A box worked out twice could come out a pixel apart if the compiler contracted the
 // two copies of the arithmetic differently, so the list builders widen theirs by one pixel and the
 // forward tests the stored box again.
-constexpr int kStageFloats = kListThreads * 9;
+constexpr int kStageFloats = kFusedThreads * 9;
 __host__ __device__ inline size_t lists_lds_bytes(int F) { return ((size_t)F * 10 + 15) & ~(size_t)15; }
 
-__global__ __launch_bounds__(kListThreads) void raster_setup_lists_kernel(
+__global__ __launch_bounds__(kFusedThreads) void raster_setup_lists_kernel(
     DevParams P, const float *__restrict__ fv, float4 *__restrict__ rec, uint2 *__restrict__ pbox,
     float4 *__restrict__ srec, int *__restrict__ tcount, unsigned short *__restrict__ tlist, int bins_x,
     int tiles_x, int setup_wgs)
@@ -1237,22 +1269,22 @@ __global__ __launch_bounds__(kListThreads) void raster_setup_lists_kernel(
     const float *src = fv + (size_t)b * P.F * 9;
     float nxt[9];
     auto fetch = [&](int f0) {
-        const int n9 = min(kListThreads, P.F - f0) * 9;
+        const int n9 = min(kFusedThreads, P.F - f0) * 9;
 #pragma unroll
         for (int k = 0; k < 9; ++k) {
-            const int i = k * kListThreads + (int)threadIdx.x;
+            const int i = k * kFusedThreads + (int)threadIdx.x;
             nxt[k] = i < n9 ? src[(size_t)f0 * 9 + i] : 0.f;
         }
     };
     fetch(0);
     auto stage = [&](int f0) {                  // the loop's closing barrier has freed s_fv
 #pragma unroll
-        for (int k = 0; k < 9; ++k) s_fv[k * kListThreads + threadIdx.x] = nxt[k];
-        if (f0 + kListThreads < P.F) fetch(f0 + kListThreads);
+        for (int k = 0; k < 9; ++k) s_fv[k * kFusedThreads + threadIdx.x] = nxt[k];
+        if (f0 + kFusedThreads < P.F) fetch(f0 + kFusedThreads);
         __syncthreads();
     };
     auto box_of = [&](int f) {
-        const float *v = s_fv + (f & (kListThreads - 1)) * 9;       // stride 9 words: no bank conflicts
+        const float *v = s_fv + (f & (kFusedThreads - 1)) * 9;       // stride 9 words: no bank conflicts
         const float x0 = v[0], y0 = v[1], x1 = v[3], y1 = v[4], x2 = v[6], y2 = v[7];
         const float raw_det = cross_rounded(x1 - x0, y1 - y0, x2 - x0, y2 - y0);
         int col0, col1, row0, row1;
@@ -1260,7 +1292,7 @@ __global__ __launch_bounds__(kListThreads) void raster_setup_lists_kernel(
         if (col0 <= col1) { col0 -= 1; col1 += 1; row0 -= 1; row1 += 1; }
         return pack_box(col0, col1, row0, row1);
     };
-    tile_lists_of_bin(P, b, (int)blockIdx.x - setup_wgs, s_dyn_list, stage, box_of, tcount, tlist, bins_x, tiles_x);
+    tile_lists_of_bin<kFusedThreads, 1>(P, b, (int)blockIdx.x - setup_wgs, s_dyn_list, stage, box_of, tcount, tlist, bins_x, tiles_x);
 }
 
 // Tile-relative record of a face from its oriented silhouette record (e_k = Ax, Ay, Sx, Sy; the end
@@ -1873,9 +1905,7 @@ __global__ __launch_bounds__(kThreads) void raster_backward_kernel(
         trace_tb = __builtin_amdgcn_s_memrealtime();
     }
 #endif
-    for (int base = half * 64; base < span_total; base += kStride) {
-        const PixIn in = nxt;
-        if (base + kStride < span_total) nxt = fetch(base + kStride);   // wave-uniform
+    auto evaluate = [&](const PixIn &in) {
         const float xp = in.xp, yp = in.yp;
         const bool valid = in.valid;
         // fold the gradient with the aggregates: g_alpha A and g_k / ssum (silhouettes: the
@@ -1987,6 +2017,33 @@ __global__ __launch_bounds__(kThreads) void raster_backward_kernel(
         acc[0] = fmaf(f0, g.dx, acc[0]); acc[1] = fmaf(f0, g.dy, acc[1]);
         acc[3] = fmaf(f1, g.dx, acc[3]); acc[4] = fmaf(f1, g.dy, acc[4]);
         acc[6] = fmaf(f2, g.dx, acc[6]); acc[7] = fmaf(f2, g.dy, acc[7]);
+    };
+    if (SV3D_BWD_UNROLL && MODE == SV3D_TEX_NONE) {
+        // Two steps per trip, each with its own set of input registers: with one set the inputs
+        // requested during a step have to be copied into place for the next one (the silhouette
+        // step is short enough for those copies to show).
+        int base = half * 64;
+        if (base < span_total) {
+            PixIn other;
+            for (;;) {                                                  // every test is wave-uniform
+                const bool more = base + kStride < span_total;
+                if (more) other = fetch(base + kStride);
+                evaluate(nxt);
+                if (!more) break;
+                base += kStride;
+                const bool more2 = base + kStride < span_total;
+                if (more2) nxt = fetch(base + kStride);
+                evaluate(other);
+                if (!more2) break;
+                base += kStride;
+            }
+        }
+    } else {
+        for (int base = half * 64; base < span_total; base += kStride) {
+            const PixIn in = nxt;
+            if (base + kStride < span_total) nxt = fetch(base + kStride);   // wave-uniform
+            evaluate(in);
+        }
     }
     }
 
@@ -2261,7 +2318,7 @@ int raster_forward_impl(const sv3d_raster_params *p, const float *face_vertices,
     if (fused) {
         const int bx = coarse_bins_x(d), nbins = bx * bx, setup_wgs = (d.F + kThreads - 1) / kThreads;
         const dim3 fgrid((unsigned)(setup_wgs + nbins), (unsigned)d.B);
-        hipLaunchKernelGGL(raster_setup_lists_kernel, fgrid, dim3(kListThreads),
+        hipLaunchKernelGGL(raster_setup_lists_kernel, fgrid, dim3(kFusedThreads),
                            lists_lds_bytes(d.F) + kStageFloats * sizeof(float), s, d, face_vertices, rec, pbox, srec,
                            tcount, tlist, bx, tiles, setup_wgs);
     } else if (mesh) {
