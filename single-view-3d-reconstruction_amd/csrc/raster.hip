@@ -94,6 +94,9 @@ constexpr int kTile = 16;         // tile side in raster pixels
 #ifndef SV3D_BWD_UNROLL
 #define SV3D_BWD_UNROLL 1                           // silhouette backward: two steps per loop trip
 #endif
+#ifndef SV3D_BINNING_LISTS_MIN_TILES
+#define SV3D_BINNING_LISTS_MIN_TILES 4096           // other launches above this many tiles: lists instead of binning
+#endif
 #ifndef SV3D_TILED_MIN_TILES
 #define SV3D_TILED_MIN_TILES 4096                   // launches above this many tiles take the lists
 #endif
@@ -620,6 +623,10 @@ struct CoarseBins {
     const unsigned short *list;                 // [B][nbins][cap] face ids, ascending; nullptr = not used
     const int *count;                           // [B][nbins]
     int bins_x, nbins, cap;
+    // per-tile lists made by raster_tile_lists_kernel (nullptr = not used): a tile whose list holds
+    // all its faces takes them from there and bins nothing
+    const int *tile_count;                      // [B][tiles][tiles]
+    const unsigned short *tile_list;            // [B][tiles][tiles][kListCap] face ids, ascending
 };
 
 __global__ __launch_bounds__(kThreads) void raster_coarse_kernel(
@@ -908,6 +915,16 @@ __attribute__((amdgpu_waves_per_eu(MODE == SV3D_TEX_VERTEX8 ? 7 : 8))) void rast
         ncand = CB.count[bi];
     }
     SV3D_STAMP(0);
+    if (CB.tile_count != nullptr) {                                     // uniform over the launch
+        const size_t tile = ((size_t)b * tiles_x + tile_y) * tiles_x + tile_x;
+        const int n = CB.tile_count[tile];                              // uniform over the workgroup
+        if (n <= kListCap) {
+            if ((int)threadIdx.x < n) s_ids[threadIdx.x] = CB.tile_list[tile * kListCap + threadIdx.x];
+            __syncthreads();
+            if (n > 0) process_list(n, true);
+            ncand = 0;                                                  // nothing left to bin
+        }
+    }
     for (int fbase = 0; fbase < ncand; fbase += 64 * 64) {
         const int nmask = (min(ncand - fbase, 64 * 64) + 63) >> 6;  // at most 64 masks per pass
         if (!COARSE && !kDirectBoxes) {
@@ -1131,6 +1148,7 @@ __attribute__((amdgpu_waves_per_eu(MODE == SV3D_TEX_VERTEX8 ? 7 : 8))) void rast
 // Layout: [Sx0 Sy0 S00 S10] [H00 Sx1 Sy1 S01] [S11 H01 Sx2 Sy2] [S02 S12 H02 box], box = the
 // face's pixel box inside the tile, four 4-bit fields (col0, col1, row0, row1; 0..15).
 constexpr int kTileCap = 128;                   // records per tile slot
+static_assert(kTileCap == kListCap, "a tile's list fills one window of the general forward kernel");
 
 constexpr int kTRecPad4 = 5;                    // LDS stride (80 B): lane-strided b128 reads are conflict free
 
@@ -2217,13 +2235,23 @@ inline long launch_tiles(const DevParams &d)
 inline bool tiled_fused(const DevParams &d) { return launch_tiles(d) <= SV3D_TILED_FUSED_MAX_TILES; }
 // Lists hold 128 faces; a tile with more goes through all of the image's faces instead, so a mesh
 // with many faces per tile (a coarse raster) keeps the binning forward.
-inline bool tiled_enabled(const DevParams &d)
+inline bool lists_fit(const DevParams &d)
 {
     const long tiles = (d.S + kTile - 1) / kTile;
-    return SV3D_TILED && d.mode == SV3D_TEX_NONE && d.alpha_fast &&
+    return SV3D_TILED && d.F <= 6000 && (long)d.F <= SV3D_TILED_MAX_FACES_PER_TILE * tiles * tiles;
+}
+// the silhouette forward over tile-relative records
+inline bool tiled_enabled(const DevParams &d)
+{
+    return lists_fit(d) && d.mode == SV3D_TEX_NONE && d.alpha_fast &&
            (launch_tiles(d) > SV3D_TILED_MIN_TILES || tiled_fused(d)) &&
-           d.F <= 6000 && (long)d.F <= SV3D_TILED_MAX_FACES_PER_TILE * tiles * tiles &&
            d.c_scale * (float)kTile * d.inv_S <= 64.f;
+}
+// Every other large launch (the colour modes: their depth softmax needs the barycentrics the
+// corner-relative records give) takes the lists in place of its tiles' own binning, nothing else.
+inline bool binning_lists_enabled(const DevParams &d)
+{
+    return lists_fit(d) && !tiled_enabled(d) && launch_tiles(d) > SV3D_BINNING_LISTS_MIN_TILES;
 }
 inline bool tiled_halves(const DevParams &d)
 {
@@ -2232,10 +2260,12 @@ inline bool tiled_halves(const DevParams &d)
 }
 inline size_t tiled_bytes(const DevParams &d)
 {
-    if (!tiled_enabled(d)) return 0;
+    const bool tiled = tiled_enabled(d);
+    if (!tiled && !binning_lists_enabled(d)) return 0;
     const size_t tiles = (size_t)((d.S + kTile - 1) / kTile);
     const size_t nt = (size_t)d.B * tiles * tiles;
-    return nt * sizeof(int) + 16 + (size_t)d.B * d.F * 3 * sizeof(float4) + nt * kTileCap * sizeof(unsigned short);
+    return nt * sizeof(int) + 16 + (tiled ? (size_t)d.B * d.F * 3 * sizeof(float4) : 0) +
+           nt * kTileCap * sizeof(unsigned short);
 }
 
 inline int launch_status()
@@ -2294,7 +2324,8 @@ int raster_forward_impl(const sv3d_raster_params *p, const float *face_vertices,
     // vertices once more per bin, and such calls come through the operators, bound by the host)
     const bool fused = tiled_enabled(d) && tiled_fused(d) && !mesh;
     const bool tiled = tiled_enabled(d) && (fused || launch_tiles(d) > SV3D_TILED_MIN_TILES);
-    const bool coarse = coarse_enabled(d) && !tiled;
+    const bool blists = binning_lists_enabled(d);
+    const bool coarse = coarse_enabled(d) && !tiled && !blists;
     // two waves per block while the grid is small enough that single waves set the kernel's span
     const bool split = (long)tiles * tiles * d.B <= SV3D_SPLIT_MAX_TILES;      // measured: 12 and 16 images of 256^2 are faster unsplit
     // group boxes are read by the large launches without coarse bins or per-tile lists only
@@ -2302,12 +2333,13 @@ int raster_forward_impl(const sv3d_raster_params *p, const float *face_vertices,
     int *tcount = nullptr;
     float4 *srec = nullptr;
     unsigned short *tlist = nullptr;
-    if (tiled) {
+    if (tiled || blists) {
         const size_t nt = (size_t)d.B * tiles * tiles;
         char *tbase = reinterpret_cast<char *>(gbox + group_boxes(d)) + coarse_bytes(d);
         tcount = reinterpret_cast<int *>(tbase);
-        srec = reinterpret_cast<float4 *>((reinterpret_cast<uintptr_t>(tbase + nt * sizeof(int)) + 15) & ~(uintptr_t)15);
-        tlist = reinterpret_cast<unsigned short *>(srec + (size_t)d.B * d.F * 3);
+        float4 *after = reinterpret_cast<float4 *>((reinterpret_cast<uintptr_t>(tbase + nt * sizeof(int)) + 15) & ~(uintptr_t)15);
+        if (tiled) srec = after;
+        tlist = reinterpret_cast<unsigned short *>(after + (tiled ? (size_t)d.B * d.F * 3 : 0));
     }
     MeshArgs m = {};
     if (mesh) {
@@ -2328,14 +2360,21 @@ int raster_forward_impl(const sv3d_raster_params *p, const float *face_vertices,
         hipLaunchKernelGGL(raster_setup_kernel, sgrid, dim3(kThreads), 0, s, d, face_vertices, rec, pbox, gbox_setup, srec);
     }
     float *saved = static_cast<float *>(pixel_saved);
-    CoarseBins cb = {nullptr, nullptr, 0, 0, 0};
+    CoarseBins cb = {nullptr, nullptr, 0, 0, 0, nullptr, nullptr};
     if (coarse) {
         const int bx = coarse_bins_x(d), nbins = bx * bx, cap = coarse_cap(d);
         int *count = reinterpret_cast<int *>(gbox + group_boxes(d));
         unsigned short *list = reinterpret_cast<unsigned short *>(count + (size_t)d.B * nbins);
         hipLaunchKernelGGL(raster_coarse_kernel, dim3((unsigned)(d.B * nbins)), dim3(kThreads), 0, s, d, pbox,
                            list, count, bx, nbins, cap);
-        cb = {list, count, bx, nbins, cap};
+        cb = {list, count, bx, nbins, cap, nullptr, nullptr};
+    }
+    if (blists) {
+        const int bx = coarse_bins_x(d);
+        hipLaunchKernelGGL(raster_tile_lists_kernel, dim3((unsigned)(bx * bx), (unsigned)d.B), dim3(kListThreads),
+                           lists_lds_bytes(d.F), s, d, pbox, tcount, tlist, bx, tiles);
+        cb.tile_count = tcount;
+        cb.tile_list = tlist;
     }
     if (tiled) {
         const int bx = coarse_bins_x(d);

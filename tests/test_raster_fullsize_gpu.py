@@ -232,6 +232,20 @@ def test_tiled_forward_with_more_faces_in_a_tile_than_a_list_holds(B):
     assert w["img"] < TOL
 
 
+def test_colour_launch_whose_tile_lists_overflow():
+    """The colour modes take the per-tile lists in place of their tiles' own binning from 4096 tiles
+    on; a tile with more faces than a list holds bins for itself as before.  Five images of the
+    5120-face mesh drawn small: both kinds of tile in one launch."""
+    verts, faces = load_mesh(4)
+    B = 5
+    fv = camera_space_faces(verts, faces, B, seed=13)
+    fv[..., :2] *= 0.2
+    fv[..., 1] -= 0.3
+    tex = _textures("vertex", B, faces.shape[0], 1)
+    sampled_compare("lists_overflow_vertex_hd_small_512", fv, tex, 512, False, "vertex", 192, check_images=(0, 4),
+                    sigma=3e-5, gamma=1e-3)
+
+
 @pytest.mark.parametrize("B,img,aa,sub,sigma", [
     (8, 256, False, 3, 1e-4),       # the benchmark configuration: 2048 tiles, two waves per block
     (12, 256, False, 3, 1e-4),      # 3072 tiles of a mesh with five faces per tile: still two waves per block
