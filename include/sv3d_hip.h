@@ -152,6 +152,12 @@ int sv3d_raster_backward_timed_n(const sv3d_raster_params *p, const float *textu
                                  float *grad_textures, void *workspace, size_t workspace_bytes,
                                  void *stream, void *ev_start, void *ev_stop, int32_t repeats);
 
+/* Name of the kernel the events of sv3d_raster_forward_timed(_n) bracket for this configuration
+ * ("raster_forward_kernel" or "raster_forward_tiled_kernel"; from_mesh != 0: as called through
+ * sv3d_render_forward), so that a benchmark can match its timings with a profiler's rows.  ""
+ * for parameters the other entry points refuse.  No counterpart in the reference. */
+const char *sv3d_raster_forward_kernel_name(const sv3d_raster_params *p, int32_t from_mesh);
+
 /* Replaces chamferdist's forward as called at nnutils/loss_utils.py:85-86
  * (`ChamferDistance()(xyz1, xyz2)`).
  *   xyz1 [B,N,3], xyz2 [B,M,3] -> dist1 [B,N], dist2 [B,M] (SQUARED distances),

@@ -2268,6 +2268,25 @@ inline size_t tiled_bytes(const DevParams &d)
            nt * kTileCap * sizeof(unsigned short);
 }
 
+// Which kernels a forward call runs.
+struct ForwardRoute {
+    bool fused;     // setup and lists in one launch (small silhouette launches from face_vertices)
+    bool tiled;     // the silhouette forward over per-tile lists and tile-relative records
+    bool blists;    // the general forward with per-tile lists in place of its binning
+    bool coarse;    // the general forward over coarse bins
+};
+// (small launches take the lists from face_vertices only: a list builder would have to project the
+// mesh's vertices once more per bin, and such calls come through the operators, bound by the host)
+inline ForwardRoute forward_route(const DevParams &d, bool from_mesh)
+{
+    ForwardRoute r;
+    r.fused = tiled_enabled(d) && tiled_fused(d) && !from_mesh;
+    r.tiled = tiled_enabled(d) && (r.fused || launch_tiles(d) > SV3D_TILED_MIN_TILES);
+    r.blists = binning_lists_enabled(d);
+    r.coarse = coarse_enabled(d) && !r.tiled && !r.blists;
+    return r;
+}
+
 inline int launch_status()
 {
     return hipGetLastError() == hipSuccess ? SV3D_OK : SV3D_ERR_LAUNCH;
@@ -2320,12 +2339,8 @@ int raster_forward_impl(const sv3d_raster_params *p, const float *face_vertices,
     const int tiles = (d.S + kTile - 1) / kTile;
     // per-tile lists: counts [B][tiles][tiles], then (16-byte aligned) the faces' oriented silhouette
     // records, then the tiles' lists of face ids
-    // (small launches from face_vertices only: a list builder would have to project the mesh's
-    // vertices once more per bin, and such calls come through the operators, bound by the host)
-    const bool fused = tiled_enabled(d) && tiled_fused(d) && !mesh;
-    const bool tiled = tiled_enabled(d) && (fused || launch_tiles(d) > SV3D_TILED_MIN_TILES);
-    const bool blists = binning_lists_enabled(d);
-    const bool coarse = coarse_enabled(d) && !tiled && !blists;
+    const ForwardRoute route = forward_route(d, mesh != nullptr);
+    const bool fused = route.fused, tiled = route.tiled, blists = route.blists, coarse = route.coarse;
     // two waves per block while the grid is small enough that single waves set the kernel's span
     const bool split = (long)tiles * tiles * d.B <= SV3D_SPLIT_MAX_TILES;      // measured: 12 and 16 images of 256^2 are faster unsplit
     // group boxes are read by the large launches without coarse bins or per-tile lists only
@@ -2529,6 +2544,13 @@ extern "C" int sv3d_raster_backward_timed(const sv3d_raster_params *p, const flo
     return raster_backward_impl(p, textures, face_rec, pixel_saved, grad_rgba, grad_face_vertices,
                                 grad_textures, workspace, workspace_bytes, stream,
                                 static_cast<hipEvent_t>(ev_start), static_cast<hipEvent_t>(ev_stop));
+}
+
+extern "C" const char *sv3d_raster_forward_kernel_name(const sv3d_raster_params *p, int32_t from_mesh)
+{
+    DevParams d;
+    if (make_dev_params(p, d) != SV3D_OK) return "";
+    return forward_route(d, from_mesh != 0).tiled ? "raster_forward_tiled_kernel" : "raster_forward_kernel";
 }
 
 extern "C" int sv3d_raster_forward_timed_n(const sv3d_raster_params *p, const float *face_vertices,

@@ -16,7 +16,7 @@ SV3D_BWD_AUTO, SV3D_BWD_BOXES, SV3D_BWD_INTERVALS = 0, 1, 2
 EXPORTS = (
     "sv3d_strerror", "sv3d_abi_version", "sv3d_raster_sizes", "sv3d_raster_forward",
     "sv3d_raster_backward", "sv3d_raster_forward_timed", "sv3d_raster_backward_timed",
-    "sv3d_raster_forward_timed_n", "sv3d_raster_backward_timed_n",
+    "sv3d_raster_forward_timed_n", "sv3d_raster_backward_timed_n", "sv3d_raster_forward_kernel_name",
     "sv3d_chamfer_forward", "sv3d_chamfer_backward",
     "sv3d_face_gather", "sv3d_face_scatter",
     "sv3d_project_gather", "sv3d_project_scatter", "sv3d_render_forward",
@@ -99,8 +99,10 @@ def lib():
         L.sv3d_project_gather.argtypes = [mp, i32, i32, vp, vp]
         L.sv3d_project_scatter.argtypes = [mp, i32, i32, vp, vp, vp, vp]
         L.sv3d_render_forward.argtypes = [pp, mp, vp, vp, vp, vp, vp, vp]
+        L.sv3d_raster_forward_kernel_name.argtypes = [pp, i32]
+        L.sv3d_raster_forward_kernel_name.restype = ctypes.c_char_p
         for name in EXPORTS:
-            if name != "sv3d_strerror":
+            if name not in ("sv3d_strerror", "sv3d_raster_forward_kernel_name"):
                 getattr(L, name).restype = ctypes.c_int
         _lib = L
     return _lib

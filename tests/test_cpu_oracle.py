@@ -208,11 +208,19 @@ def test_c_abi_argument_validation_without_gpu():
     from sv3d import _lib
     p = _lib.make_params(8, 1280, 256, 1, 0, 1, True, (0, 0, 0), 1, 100, 1e-3, 1e-4, 1e-10, 1e-4)
     rec, saved, ws = _lib.raster_sizes(p)
-    # per face a 128-byte record and an 8-byte pixel box, per group of 64 faces an 8-byte box
-    assert rec == 8 * 1280 * (32 * 4 + 8) + 8 * 20 * 8 and saved == 8 * 256 * 256 * 4 and ws == 0
+    # per face a 128-byte record and an 8-byte pixel box, per group of 64 faces an 8-byte box; a
+    # silhouette launch also holds per tile (8 images x 16 x 16) a count and 128 16-bit face ids, and
+    # per face a 48-byte oriented record (16-byte aligned behind the counts)
+    plain = 8 * 1280 * (32 * 4 + 8) + 8 * 20 * 8
+    assert rec == plain + 8 * 256 * 4 + 16 + 8 * 1280 * 48 + 8 * 256 * 128 * 2
+    assert saved == 8 * 256 * 256 * 4 and ws == 0
+    assert _lib.lib().sv3d_raster_forward_kernel_name(ctypes.byref(p), 0) == b"raster_forward_tiled_kernel"
+    assert _lib.lib().sv3d_raster_forward_kernel_name(ctypes.byref(p), 1) == b"raster_forward_kernel"
     p.texture_mode = 1
     p.texture_res = 6
-    assert _lib.raster_sizes(p)[1:] == (8 * 256 * 256 * 6 * 4, 0)        # no backward scratch in any mode
+    # a colour launch of this size keeps the plain layout (lists from 4096 tiles on)
+    assert _lib.raster_sizes(p) == (plain, 8 * 256 * 256 * 6 * 4, 0)       # no backward scratch in any mode
+    assert _lib.lib().sv3d_raster_forward_kernel_name(ctypes.byref(p), 0) == b"raster_forward_kernel"
     bad = _lib.make_params(0, 1280, 256, 1, 0, 1, True, (0, 0, 0), 1, 100, 1e-3, 1e-4, 1e-10, 1e-4)
     with pytest.raises(_lib.Sv3dError):
         _lib.raster_sizes(bad)
