@@ -1269,7 +1269,9 @@ __global__ __launch_bounds__(kListThreads) void raster_tile_lists_kernel(
 // looked at.  A box worked out twice could come out a pixel apart if the compiler contracted the
 // two copies of the arithmetic differently, so the list builders widen theirs by one pixel and the
 // forward tests the stored box again.
-constexpr int kStageFloats = kFusedThreads * 9;
+constexpr int kFusedFaces = 2;                  // faces per thread per pass: 2048 per workgroup
+constexpr int kStageFaces = kFusedThreads * kFusedFaces;
+constexpr int kStageFloats = kStageFaces * 9;
 __host__ __device__ inline size_t lists_lds_bytes(int F) { return ((size_t)F * 10 + 15) & ~(size_t)15; }
 
 __global__ __launch_bounds__(kFusedThreads) void raster_setup_lists_kernel(
@@ -1285,11 +1287,12 @@ __global__ __launch_bounds__(kFusedThreads) void raster_setup_lists_kernel(
     }
     float *s_fv = reinterpret_cast<float *>(reinterpret_cast<char *>(s_dyn_list) + lists_lds_bytes(P.F));
     const float *src = fv + (size_t)b * P.F * 9;
-    float nxt[9];
+    constexpr int kLoads = 9 * kFusedFaces;     // per thread and pass, all in flight together
+    float nxt[kLoads];
     auto fetch = [&](int f0) {
-        const int n9 = min(kFusedThreads, P.F - f0) * 9;
+        const int n9 = min(kStageFaces, P.F - f0) * 9;
 #pragma unroll
-        for (int k = 0; k < 9; ++k) {
+        for (int k = 0; k < kLoads; ++k) {
             const int i = k * kFusedThreads + (int)threadIdx.x;
             nxt[k] = i < n9 ? src[(size_t)f0 * 9 + i] : 0.f;
         }
@@ -1297,12 +1300,12 @@ __global__ __launch_bounds__(kFusedThreads) void raster_setup_lists_kernel(
     fetch(0);
     auto stage = [&](int f0) {                  // the loop's closing barrier has freed s_fv
 #pragma unroll
-        for (int k = 0; k < 9; ++k) s_fv[k * kFusedThreads + threadIdx.x] = nxt[k];
-        if (f0 + kFusedThreads < P.F) fetch(f0 + kFusedThreads);
+        for (int k = 0; k < kLoads; ++k) s_fv[k * kFusedThreads + threadIdx.x] = nxt[k];
+        if (f0 + kStageFaces < P.F) fetch(f0 + kStageFaces);
         __syncthreads();
     };
     auto box_of = [&](int f) {
-        const float *v = s_fv + (f & (kFusedThreads - 1)) * 9;       // stride 9 words: no bank conflicts
+        const float *v = s_fv + (f & (kStageFaces - 1)) * 9;         // stride 9 words: no bank conflicts
         const float x0 = v[0], y0 = v[1], x1 = v[3], y1 = v[4], x2 = v[6], y2 = v[7];
         const float raw_det = cross_rounded(x1 - x0, y1 - y0, x2 - x0, y2 - y0);
         int col0, col1, row0, row1;
@@ -1310,7 +1313,7 @@ __global__ __launch_bounds__(kFusedThreads) void raster_setup_lists_kernel(
         if (col0 <= col1) { col0 -= 1; col1 += 1; row0 -= 1; row1 += 1; }
         return pack_box(col0, col1, row0, row1);
     };
-    tile_lists_of_bin<kFusedThreads, 1>(P, b, (int)blockIdx.x - setup_wgs, s_dyn_list, stage, box_of, tcount, tlist, bins_x, tiles_x);
+    tile_lists_of_bin<kFusedThreads, kFusedFaces>(P, b, (int)blockIdx.x - setup_wgs, s_dyn_list, stage, box_of, tcount, tlist, bins_x, tiles_x);
 }
 
 // Tile-relative record of a face from its oriented silhouette record (e_k = Ax, Ay, Sx, Sy; the end
