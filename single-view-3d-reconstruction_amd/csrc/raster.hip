@@ -431,10 +431,11 @@ __device__ inline uint2 pack_box(int col0, int col1, int row0, int row1)
                       (uint32_t)(row0 & 0xffff) | ((uint32_t)(row1 & 0xffff) << 16));
 }
 
+// r: where the face's record goes (8 float4); q: its oriented silhouette record (3 float4) or nullptr.
 __device__ inline void setup_face(const DevParams &P, int gid, float x0, float y0, float z0, float x1,
                                   float y1, float z1, float x2, float y2, float z2, float zref,
-                                  float4 *__restrict__ rec, uint2 *__restrict__ pbox, int &col0, int &col1,
-                                  int &row0, int &row1, float4 *__restrict__ srec = nullptr)
+                                  float4 *__restrict__ r, uint2 *__restrict__ pbox, int &col0, int &col1,
+                                  int &row0, int &row1, float4 *__restrict__ q)
 {
     const float e0x = x1 - x0, e0y = y1 - y0;
     const float e1x = x2 - x1, e1y = y2 - y1;
@@ -447,7 +448,6 @@ __device__ inline void setup_face(const DevParams &P, int gid, float x0, float y
     face_box(P, x0, y0, x1, y1, x2, y2, raw_det, col0, col1, row0, row1);
     const uint2 box = pack_box(col0, col1, row0, row1);
     const float iz0 = 1.f / z0, iz1 = 1.f / z1, iz2 = 1.f / z2;
-    float4 *r = rec + (size_t)gid * kRec4;
     r[0] = make_float4(x0, y0, x1, y1);
     r[1] = make_float4(x2, y2, e0x, e0y);
     r[2] = make_float4(e1x, e1y, e2x, e2y);
@@ -460,11 +460,10 @@ __device__ inline void setup_face(const DevParams &P, int gid, float x0, float y
                        __int_as_float(raw_det < 0.f ? 1 : 0), zref);
     r[7] = make_float4(__uint_as_float(box.x), __uint_as_float(box.y), e2x * inv_det, e2y * inv_det);
     pbox[gid] = box;
-    if (srec) {
+    if (q) {
         // Oriented silhouette record (per-tile lists): the three edges taken so that the inside is on
         // their left -- for a face of the other orientation the corners go round the other way --
         // each as its start point and c times its unit direction, c = sqrt(log2(e) / sigma).
-        float4 *q = srec + (size_t)gid * 3;
         if (raw_det > 0.f) {
             q[0] = oriented_edge(x0, y0, x1, y1, P.c_scale);
             q[1] = oriented_edge(x1, y1, x2, y2, P.c_scale);
@@ -501,18 +500,56 @@ __device__ inline void store_group_box(const DevParams &P, int b, int f, bool va
                        (uint32_t)(r0 & 0xffff) | ((uint32_t)(r1 & 0xffff) << 16));
 }
 
+// A thread's record is 128 bytes, its oriented record 48: stored by the thread that made them, every
+// store instruction of a wave would touch 64 cache lines with 16 bytes each.  The records go through
+// LDS instead (per wave: 64 records at a stride of nine float4, conflict free, and 64 x 3 float4 of
+// oriented records as they lie) and leave as the 8 KB and 3 KB blocks they form in memory, one
+// kilobyte per instruction.  kSetupStage4: float4 per wave.
+constexpr int kSetupStageRec4 = 64 * (kRec4 + 1);
+constexpr int kSetupStage4 = kSetupStageRec4 + 64 * 3;
+
+// The wave's records out of its staging area: faces f0 .. f0 + 63 of image b, `f0` the face of lane 0.
+__device__ inline void store_staged_records(const DevParams &P, int b, int f0, const float4 *s_wave,
+                                            float4 *__restrict__ rec, float4 *__restrict__ srec)
+{
+    const int lane = threadIdx.x & 63;
+    const int nvalid = min(64, P.F - f0);               // <= 0: a wave past the image's faces
+    __builtin_amdgcn_wave_barrier();                    // the wave's own LDS writes are in order before its reads
+    float4 *dst = rec + ((size_t)b * P.F + f0) * kRec4;
+#pragma unroll
+    for (int i = 0; i < kRec4; ++i) {
+        const int qi = i * 64 + lane, face = qi >> 3, part = qi & 7;
+        const float4 v = s_wave[face * (kRec4 + 1) + part];
+        if (face < nvalid) dst[qi] = v;
+    }
+    if (srec) {
+        float4 *dq = srec + ((size_t)b * P.F + f0) * 3;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int qi = i * 64 + lane;
+            const float4 v = s_wave[kSetupStageRec4 + qi];
+            if (qi < 3 * nvalid) dq[qi] = v;
+        }
+    }
+}
+
+// s_stage: kSetupStage4 float4 of LDS for each wave of the workgroup that calls this.
 __device__ inline void setup_from_face_vertices(
     const DevParams &P, int b, int f, const float *__restrict__ fv, float4 *__restrict__ rec,
-    uint2 *__restrict__ pbox, uint2 *__restrict__ gbox, float4 *__restrict__ srec)
+    uint2 *__restrict__ pbox, uint2 *__restrict__ gbox, float4 *__restrict__ srec, float4 *s_stage)
 {
     const bool valid = f < P.F;
+    const int lane = threadIdx.x & 63;
+    float4 *s_wave = s_stage + (threadIdx.x >> 6) * kSetupStage4;
     int col0 = 32767, col1 = -1, row0 = 32767, row1 = -1;
     if (valid) {
         const int gid = b * P.F + f;
         const float *v = fv + (size_t)gid * 9;
         setup_face(P, gid, v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], v[8],
-                   fv[(size_t)b * P.F * 9 + 2], rec, pbox, col0, col1, row0, row1, srec);
+                   fv[(size_t)b * P.F * 9 + 2], s_wave + lane * (kRec4 + 1), pbox, col0, col1, row0, row1,
+                   srec ? s_wave + kSetupStageRec4 + lane * 3 : nullptr);
     }
+    store_staged_records(P, b, f - lane, s_wave, rec, srec);
     if (gbox) store_group_box(P, b, f, valid, col0, col1, row0, row1, gbox);
 }
 
@@ -521,7 +558,8 @@ __global__ __launch_bounds__(kThreads) void raster_setup_kernel(
     uint2 *__restrict__ gbox,                   // gbox == nullptr: the forward will not read group boxes
     float4 *__restrict__ srec)                  // oriented silhouette records, or nullptr
 {
-    setup_from_face_vertices(P, blockIdx.y, blockIdx.x * kThreads + threadIdx.x, fv, rec, pbox, gbox, srec);
+    __shared__ float4 s_stage[(kThreads / 64) * kSetupStage4];
+    setup_from_face_vertices(P, blockIdx.y, blockIdx.x * kThreads + threadIdx.x, fv, rec, pbox, gbox, srec, s_stage);
 }
 
 // Setup straight from the object-space mesh: each thread projects its face's three vertices
@@ -551,9 +589,11 @@ __device__ inline void project_face(const MeshArgs &m, int F, int b, int f, floa
 
 __device__ inline void setup_from_mesh(
     const DevParams &P, const MeshArgs &m, int b, int f, float *__restrict__ fv_out, float4 *__restrict__ rec,
-    uint2 *__restrict__ pbox, uint2 *__restrict__ gbox, float4 *__restrict__ srec)
+    uint2 *__restrict__ pbox, uint2 *__restrict__ gbox, float4 *__restrict__ srec, float4 *s_stage)
 {
     const bool valid = f < P.F;
+    const int lane = threadIdx.x & 63;
+    float4 *s_wave = s_stage + (threadIdx.x >> 6) * kSetupStage4;
     int col0 = 32767, col1 = -1, row0 = 32767, row1 = -1;
     if (valid) {
     const int gid = b * P.F + f;
@@ -569,9 +609,10 @@ __device__ inline void setup_from_mesh(
 #pragma unroll
         for (int i = 0; i < 9; ++i) fv_out[(size_t)gid * 9 + i] = o[i];
     }
-    setup_face(P, gid, o[0], o[1], o[2], o[3], o[4], o[5], o[6], o[7], o[8], zref, rec, pbox, col0, col1,
-               row0, row1, srec);
+    setup_face(P, gid, o[0], o[1], o[2], o[3], o[4], o[5], o[6], o[7], o[8], zref, s_wave + lane * (kRec4 + 1),
+               pbox, col0, col1, row0, row1, srec ? s_wave + kSetupStageRec4 + lane * 3 : nullptr);
     }
+    store_staged_records(P, b, f - lane, s_wave, rec, srec);
     if (gbox) store_group_box(P, b, f, valid, col0, col1, row0, row1, gbox);
 }
 
@@ -579,7 +620,8 @@ __global__ __launch_bounds__(kThreads) void raster_setup_mesh_kernel(
     DevParams P, MeshArgs m, float *__restrict__ fv_out, float4 *__restrict__ rec,
     uint2 *__restrict__ pbox, uint2 *__restrict__ gbox, float4 *__restrict__ srec)
 {
-    setup_from_mesh(P, m, blockIdx.y, blockIdx.x * kThreads + threadIdx.x, fv_out, rec, pbox, gbox, srec);
+    __shared__ float4 s_stage[(kThreads / 64) * kSetupStage4];
+    setup_from_mesh(P, m, blockIdx.y, blockIdx.x * kThreads + threadIdx.x, fv_out, rec, pbox, gbox, srec, s_stage);
 }
 
 __device__ inline void unpack_box(uint2 b, int &col0, int &col1, int &row0, int &row1)
@@ -1281,8 +1323,10 @@ __global__ __launch_bounds__(kFusedThreads) void raster_setup_lists_kernel(
 {
     const int b = blockIdx.y;
     if ((int)blockIdx.x < setup_wgs) {          // uniform over the workgroup
+        // (their records leave through the dynamic LDS the list builders use for their lists)
         if (threadIdx.x < kThreads)
-            setup_from_face_vertices(P, b, (int)blockIdx.x * kThreads + (int)threadIdx.x, fv, rec, pbox, nullptr, srec);
+            setup_from_face_vertices(P, b, (int)blockIdx.x * kThreads + (int)threadIdx.x, fv, rec, pbox, nullptr, srec,
+                                     reinterpret_cast<float4 *>(s_dyn_list));
         return;
     }
     float *s_fv = reinterpret_cast<float *>(reinterpret_cast<char *>(s_dyn_list) + lists_lds_bytes(P.F));
