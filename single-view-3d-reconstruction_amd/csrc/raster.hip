@@ -368,7 +368,10 @@ __device__ inline int texel_index(float n0, float n1, float n2, int R)
     const int wx = min((int)fx, R - 1), wy = min((int)fy, R - 1);
     // (n0 + n1) written as (1 - n2): identical in exact arithmetic, and exact on a clamped edge
     const bool lower = ((1.f - n2) * (float)R - (float)wx) - (float)wy <= 1.f;
-    return lower ? wy * R + wx : (R - 1 - wy) * R + (R - 1 - wx);
+    // R <= 36: a 24-bit multiply-add (the 32-bit one is a quarter-rate 64-bit instruction here; the
+    // masks below tell the compiler the range)
+    const int sx = lower ? wx : R - 1 - wx, sy = lower ? wy : R - 1 - wy;
+    return (int)(((unsigned)sy & 63u) * ((unsigned)R & 63u) + (unsigned)sx);
 }
 
 // ------------------------------------------------------------------------------------
@@ -914,12 +917,15 @@ __attribute__((amdgpu_waves_per_eu(MODE == SV3D_TEX_VERTEX8 ? 7 : 8))) void rast
                     float kc[NC];
 #pragma unroll
                     for (int c = 0; c < NC; ++c) kc[c] = 0.f;
+                    // the face is the same for all lanes: its textures' address is worked out once, in
+                    // scalar registers, and a lane adds a 32-bit offset
+                    const int fid = __builtin_amdgcn_readfirstlane(s_ids[jj]);
                     if (d.contrib) {
-                        const int fid = s_ids[jj];
                         if (MODE == SV3D_TEX_SURFACE) {
                             const int Ts = P.R * P.R;
-                            const float *tp = tex + (((size_t)tb * F + fid) * Ts +
-                                                     texel_index(d.n0, d.n1, d.n2, P.R)) * 3;
+                            const float *tface = tex + ((size_t)tb * F + fid) * Ts * 3;
+                            const unsigned off = __umul24((unsigned)texel_index(d.n0, d.n1, d.n2, P.R), 12u);
+                            const float *tp = reinterpret_cast<const float *>(reinterpret_cast<const char *>(tface) + off);
                             kc[0] = tp[0]; kc[1] = tp[1]; kc[2] = tp[2];
                         } else {
                             const float *tp = tex + ((size_t)tb * F + fid) * (3 * NC);
@@ -1117,9 +1123,10 @@ __attribute__((amdgpu_waves_per_eu(MODE == SV3D_TEX_VERTEX8 ? 7 : 8))) void rast
             sp[2] = make_float2(o[1], o[2]);
         } else {                                // 12 floats: A, sum, max, eight colours, pad
             float4 *sp = (float4 *)(saved + pix * 12);
-            sp[0] = make_float4(A, ssum, m, o[0]);
-            sp[1] = make_float4(o[1], o[2], o[3], o[4]);
-            sp[2] = make_float4(o[5], o[6], o[7], 0.f);
+            auto oc = [&](int i) { return o[i <= NC ? i : NC]; };     // (indices in range for every NC)
+            sp[0] = make_float4(A, ssum, m, oc(0));
+            sp[1] = make_float4(oc(1), oc(2), oc(3), oc(4));
+            sp[2] = make_float4(oc(5), oc(6), oc(7), 0.f);
         }
     }
     // planes of the image: colours then alpha, or the alpha plane alone
