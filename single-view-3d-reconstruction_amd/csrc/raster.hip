@@ -1112,17 +1112,20 @@ __attribute__((amdgpu_waves_per_eu(MODE == SV3D_TEX_VERTEX8 ? 7 : 8))) void rast
     A = fminf(A, 1.f);                          // e*rcp(1+e) may round a hair above 1
     o[NC] = 1.f - A;
     const bool inimg = col < S && row < S;
+    // (per image a base in scalar registers; per lane a 24-bit pixel index: S <= 4096)
+    constexpr int kSavedFloats = MODE == SV3D_TEX_NONE ? 1 : (NC == 3 ? 6 : 12);
+    float *saved_b = saved + (size_t)b * S * S * kSavedFloats;
     if (inimg) {
-        const size_t pix = ((size_t)b * S + row) * S + col;
+        const unsigned pix = __umul24((unsigned)row, (unsigned)S) + (unsigned)col;
         if (MODE == SV3D_TEX_NONE) {
-            saved[pix] = A;
+            saved_b[pix] = A;
         } else if (NC == 3) {
-            float2 *sp = (float2 *)(saved + pix * 6);
+            float2 *sp = (float2 *)(saved_b + pix * 6u);
             sp[0] = make_float2(A, ssum);
             sp[1] = make_float2(m, o[0]);
             sp[2] = make_float2(o[1], o[2]);
         } else {                                // 12 floats: A, sum, max, eight colours, pad
-            float4 *sp = (float4 *)(saved + pix * 12);
+            float4 *sp = (float4 *)(saved_b + pix * 12u);
             auto oc = [&](int i) { return o[i <= NC ? i : NC]; };     // (indices in range for every NC)
             sp[0] = make_float4(A, ssum, m, oc(0));
             sp[1] = make_float4(oc(1), oc(2), oc(3), oc(4));
@@ -1132,24 +1135,24 @@ __attribute__((amdgpu_waves_per_eu(MODE == SV3D_TEX_VERTEX8 ? 7 : 8))) void rast
     // planes of the image: colours then alpha, or the alpha plane alone
     const bool only_alpha = MODE == SV3D_TEX_NONE && P.alpha_only;
     const int planes = only_alpha ? 1 : NC + 1, first = only_alpha ? NC : 0;
+    const int H = __builtin_amdgcn_readfirstlane(P.aa == 2 ? S >> 1 : S);
+    const unsigned plane = (unsigned)H * (unsigned)H;
+    float *rgba_b = rgba + (size_t)b * planes * plane;
     if (P.aa == 2) {
-        const int H = S >> 1;
-        const size_t plane = (size_t)H * H;
-        const size_t ob = ((size_t)b * planes * H + (row >> 1)) * H + (col >> 1);
+        const unsigned ob = __umul24((unsigned)(row >> 1), (unsigned)H) + (unsigned)(col >> 1);
 #pragma unroll
         for (int c = 0; c <= NC; ++c) {
             if (c < first) continue;
             float v = inimg ? o[c] : 0.f;
             v += __shfl_xor(v, 1);
             v += __shfl_xor(v, 2);
-            if (sub == 0 && inimg) rgba[ob + (c - first) * plane] = 0.25f * v;
+            if (sub == 0 && inimg) (rgba_b + (size_t)(c - first) * plane)[ob] = 0.25f * v;
         }
     } else if (inimg) {
-        const size_t ob = ((size_t)b * planes * S + row) * S + col;
-        const size_t plane = (size_t)S * S;
+        const unsigned ob = __umul24((unsigned)row, (unsigned)S) + (unsigned)col;
 #pragma unroll
         for (int c = 0; c <= NC; ++c) {
-            if (c >= first) rgba[ob + (c - first) * plane] = o[c];
+            if (c >= first) (rgba_b + (size_t)(c - first) * plane)[ob] = o[c];
         }
     }
     SV3D_STAMP(6);
@@ -1511,9 +1514,10 @@ __global__ __launch_bounds__(kThreads / NB * HALVES) void raster_forward_tiled_k
 
         if (n_list <= kTileCap) {
             if ((int)threadIdx.x < n_list) {    // one thread per face of the list builds its record in LDS
-                const size_t f = (size_t)b * F + my_id;
-                const float4 *q = srec + f * 3;
-                make_tile_record(q[0], q[1], q[2], pbox[f], tile_c0, tile_r0, cx_num, cy_num, (float)S, P.inv_S,
+                // (the image's arrays from a scalar base, the face by a 32-bit offset)
+                const float4 *q = reinterpret_cast<const float4 *>(
+                    reinterpret_cast<const char *>(srec + (size_t)b * F * 3) + __umul24((unsigned)my_id, 48u));
+                make_tile_record(q[0], q[1], q[2], (pbox + (size_t)b * F)[my_id], tile_c0, tile_r0, cx_num, cy_num, (float)S, P.inv_S,
                                  &s_trec[threadIdx.x * kTRecPad4]);
             }
             process_window(n_list, true);
@@ -1548,31 +1552,34 @@ __global__ __launch_bounds__(kThreads / NB * HALVES) void raster_forward_tiled_k
     } else if (HALVES == 2 && part == 1) {
         return;
     }
+    // (per image a base in scalar registers; per lane a 24-bit index: S <= 4096)
     const bool only_alpha = P.alpha_only;
     const int planes = only_alpha ? 1 : 4;
+    float *saved_b = saved + (size_t)b * S * S;
+    const int H = __builtin_amdgcn_readfirstlane(P.aa == 2 ? S >> 1 : S);
+    const unsigned plane = (unsigned)H * (unsigned)H;
+    float *rgba_b = rgba + (size_t)b * planes * plane;
+    float *alpha_b = rgba_b + (size_t)(planes - 1) * plane;
 #pragma unroll
     for (int side = 0; side < NB; ++side) {
         const float A = fminf(side ? A1 : A0, 1.f);
         const float alpha = 1.f - A;
         const int c = col + 8 * side;
         const bool inimg = c < S && row < S;
-        if (inimg) saved[((size_t)b * S + row) * S + c] = A;
+        if (inimg) saved_b[__umul24((unsigned)row, (unsigned)S) + (unsigned)c] = A;
         if (P.aa == 2) {
-            const int H = S >> 1;
-            const size_t plane = (size_t)H * H;
-            const size_t ob = ((size_t)b * planes * H + (row >> 1)) * H + (c >> 1);
+            const unsigned ob = __umul24((unsigned)(row >> 1), (unsigned)H) + (unsigned)(c >> 1);
             float v = inimg ? alpha : 0.f;
             v += __shfl_xor(v, 1);
             v += __shfl_xor(v, 2);
             if (sub == 0 && inimg) {
-                rgba[ob + (planes - 1) * plane] = 0.25f * v;
-                if (!only_alpha) { rgba[ob] = P.bg0; rgba[ob + plane] = P.bg1; rgba[ob + 2 * plane] = P.bg2; }
+                alpha_b[ob] = 0.25f * v;
+                if (!only_alpha) { rgba_b[ob] = P.bg0; rgba_b[ob + plane] = P.bg1; rgba_b[ob + 2 * plane] = P.bg2; }
             }
         } else if (inimg) {
-            const size_t plane = (size_t)S * S;
-            const size_t ob = ((size_t)b * planes * S + row) * S + c;
-            rgba[ob + (planes - 1) * plane] = alpha;
-            if (!only_alpha) { rgba[ob] = P.bg0; rgba[ob + plane] = P.bg1; rgba[ob + 2 * plane] = P.bg2; }
+            const unsigned ob = __umul24((unsigned)row, (unsigned)S) + (unsigned)c;
+            alpha_b[ob] = alpha;
+            if (!only_alpha) { rgba_b[ob] = P.bg0; rgba_b[ob + plane] = P.bg1; rgba_b[ob + 2 * plane] = P.bg2; }
         }
     }
 }
