@@ -60,3 +60,18 @@ def elementwise_rel_err(a, b, floor=1e-3, q=0.999):
     r = ((a - b).abs() / b.abs())[big]
     k = min(r.numel() - 1, int(q * r.numel()))
     return float(torch.sort(r).values[k])
+
+
+def sliver_faces(fv, ratio=1e4):
+    """[..., F] bool: faces whose three projected corners are collinear to fp32 -- longest edge squared
+    above `ratio` times the doubled area, so that rounding the corner differences alone moves the
+    area by some 1e-3 of itself.  Their edges all but coincide; which of them is "nearest" to a pixel,
+    hence which corners the distance gradient goes to, is decided by rounding in any precision, and
+    the oracle freezes that choice as fp64 makes it.  Gradient comparisons leave such faces out (and
+    count them): one of them, carrying a thousandth of the largest gradient, is enough to reach 1e-5
+    of the largest entry."""
+    p = fv[..., :2].double()
+    e = p[..., [1, 2, 0], :] - p
+    longest2 = (e * e).sum(-1).max(-1).values
+    area2 = (e[..., 0, 0] * (p[..., 2, 1] - p[..., 0, 1]) - e[..., 0, 1] * (p[..., 2, 0] - p[..., 0, 0])).abs()
+    return longest2 > ratio * area2

@@ -15,13 +15,9 @@ same figures for the oracle's own upstream-style formulas evaluated densely in f
 inputs (what single precision costs with SoftRas's barycentric `t - w` algebra, before any kernel
 is involved): max-norm 4e-2 .. 6e-2, p999 of order 1.
 
-Sliver faces are left out of the gradient comparison (and counted): a face whose three projected
-corners are collinear to fp32 -- longest edge squared above 1e5 times its doubled area, so that
-rounding the corner differences alone moves the area by a per cent or more -- has coincident
-edges, and which of them is "nearest" to a pixel, hence which corners its distance gradient goes
-to, is decided by rounding in any precision.  The oracle freezes that choice as fp64 makes it.
-Such a face's gradient is a thousandth of the largest one; one in a random pose of the 1280-face
-sphere is enough to reach 1e-5 of the largest entry.
+Sliver faces (`helpers.sliver_faces`: three projected corners collinear to fp32, so that which of
+their all but coincident edges is "nearest" to a pixel is decided by rounding in any precision) are
+left out of the gradient comparison and counted.
 
 Sizes follow the reference's defaults (softras.py:33-37: sigma 1e-5, gamma 1e-4, anti-aliasing;
 mesh_net.py:34 tex_size 6; utils/mesh.py:13-14 subdivide 3 / 4; main.py:56 part maps).
@@ -32,7 +28,7 @@ import os
 import pytest
 import torch
 
-from helpers import camera_space_faces, elementwise_rel_err, load_mesh, rel_err
+from helpers import camera_space_faces, elementwise_rel_err, load_mesh, rel_err, sliver_faces
 from oracle import raster_oracle
 
 pytestmark = pytest.mark.gpu
@@ -87,15 +83,6 @@ def _raster_pixels(out_pix, img, aa):
     return torch.stack(sub, 1)
 
 
-def _sliver_faces(fv_b):
-    """[F] bool: faces whose projected corners are collinear to fp32 (see the module docstring)."""
-    p = fv_b[..., :2].double()
-    e = p[:, [1, 2, 0]] - p
-    longest2 = (e * e).sum(-1).max(-1).values
-    area2 = (e[:, 0, 0] * (p[:, 2, 1] - p[:, 0, 1]) - e[:, 0, 1] * (p[:, 2, 0] - p[:, 0, 0])).abs()
-    return longest2 > 1e5 * area2
-
-
 def sampled_compare(name, fv, tex, img, aa, mode, n_out, check_images=None, fp32_floor=False, **kw):
     """GPU forward + backward over the whole batch; oracle on `n_out` output pixels of every image
     in `check_images` (default: all).  Returns the worst errors."""
@@ -140,7 +127,7 @@ def sampled_compare(name, fv, tex, img, aa, mode, n_out, check_images=None, fp32
         keep = ~unstable
         e_img = float((got[b][:, out_pix].double() - want.detach())[:, keep].abs().max() / want.detach().abs().max())
         worst["img"] = max(worst["img"], e_img)
-        sliver = _sliver_faces(fv[b])
+        sliver = sliver_faces(fv[b])
         worst["sliver_faces"] += float(sliver.sum())
         err_fv = (gfv[b].double() - xb.grad).abs()[~sliver].max() / xb.grad.abs().max()
         worst["grad_fv"] = max(worst["grad_fv"], float(err_fv))

@@ -13,7 +13,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import camera_space_faces, load_mesh, rel_err
+from helpers import camera_space_faces, load_mesh, rel_err, sliver_faces
 from oracle import raster_oracle
 
 pytestmark = pytest.mark.gpu
@@ -113,9 +113,11 @@ def _compare(name, fv, tex, img, aa, mode, fp32_floor=False, grad_tol=None, img_
     assert frac < 5e-3, frac
     keep = (~unstable)[:, None].expand_as(want)
     e_img = float((got.double() - want)[keep].abs().max() / want.abs().max())
-    e_fv = rel_err(gfv, wfv)
+    # faces collinear to fp32 are left out of the gradient comparison (helpers.sliver_faces) and counted
+    sliver = sliver_faces(fv)
+    e_fv = float((gfv.double() - wfv).abs()[~sliver].max() / wfv.abs().max())
     e_tex = rel_err(gtex, wtex) if wtex is not None else 0.0
-    _record(name, img=e_img, grad_fv=e_fv, grad_tex=e_tex, unstable=frac, active=sum(nact))
+    _record(name, img=e_img, grad_fv=e_fv, grad_tex=e_tex, unstable=frac, active=sum(nact), sliver_faces=int(sliver.sum()))
     assert torch.isfinite(got).all() and torch.isfinite(gfv).all()
     sharp_softmax = mode != "none" and kw.get("gamma", 1e-4) <= 1e-4
     gtol = grad_tol if grad_tol is not None else (COLOUR_GAMMA_1E4_TOL if sharp_softmax else GRAD_TOL)
@@ -472,6 +474,26 @@ def test_parity_seeded_random_configurations(seed):
     tex = _textures(mode, B, faces.shape[0], R, seed=seed)
     _compare("sweep_%d_%s_S%d_aa%d" % (seed, mode, img, aa), fv, tex, img, aa, mode, grad_tol=SWEEP_GRAD_TOL,
              sigma=sigma, gamma=gamma, double_side=double_side, background=bgc)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_parity_silhouettes_on_the_list_route(seed):
+    """Seeded sweep over the silhouette launches that take per-tile face lists with the setup launch
+    building them: a mesh of at most eight faces per 16 x 16 tile (80 or 320 faces on rasters of 56 to
+    152 pixels, most of them no multiple of the tile, powers of two and not), one to three images,
+    with and without anti-aliasing, against the dense oracle."""
+    g = torch.Generator().manual_seed(2000 + seed)
+    pick = lambda xs: xs[int(torch.randint(len(xs), (1,), generator=g))]
+    sub, sizes = pick([(1, [56, 72, 100, 128]), (2, [104, 120, 136, 152])])
+    S = pick(sizes)
+    aa = bool(seed & 1)
+    img = S // 2 if aa else S
+    sigma = pick([1e-4, 5e-5])          # (tile-relative records need sqrt(log2 e / sigma) * 16 / S <= 64)
+    B = pick([1, 2, 3])
+    verts, faces = load_mesh(sub)
+    assert faces.shape[0] <= 8 * ((S + 15) // 16) ** 2
+    fv = camera_space_faces(verts, faces, B, seed=70 + seed)
+    _compare("lists_sweep_%d_S%d_aa%d_f%d" % (seed, S, aa, faces.shape[0]), fv, None, img, aa, "none", sigma=sigma)
 
 
 @pytest.mark.parametrize("aa", [False, True])
