@@ -174,6 +174,9 @@ struct FaceRec {
     float e0x, e0y, e1x, e1y, e2x, e2y;
     float il0, il1, il2, inv_det;
     float f0x, f0y, f1x, f1y, f2x, f2y;
+    // Colour modes: 1/z_k and (z_k - z_ref)/z_k.  Silhouette launches have no use for depth and
+    // keep -e_k / |e_k|^2 in these six floats instead (g0x, g0y, g1x, g1y, g2x, g2y in this
+    // order): the edge parameter of a pixel is then one multiply-add less per edge.
     float iz0, iz1, iz2;
     float q0, q1, q2;
     int flags;
@@ -266,7 +269,8 @@ __device__ inline Pixel make_pixel(float kx, float ky, float xp, float yp, float
     return q;
 }
 
-template <bool LO>
+// SIL: the record of a silhouette launch (see FaceRec).
+template <bool LO, bool SIL>
 __device__ inline PairGeom pair_geom(const FaceRec &r, const Pixel &px, const DevParams &P)
 {
     PairGeom g;
@@ -274,9 +278,9 @@ __device__ inline PairGeom pair_geom(const FaceRec &r, const Pixel &px, const De
     const float a0x = LO ? (r.p0x - xp) - px.xl : r.p0x - xp, a0y = LO ? (r.p0y - yp) - px.yl : r.p0y - yp;
     const float a1x = LO ? (r.p1x - xp) - px.xl : r.p1x - xp, a1y = LO ? (r.p1y - yp) - px.yl : r.p1y - yp;
     const float a2x = LO ? (r.p2x - xp) - px.xl : r.p2x - xp, a2y = LO ? (r.p2y - yp) - px.yl : r.p2y - yp;
-    const float t0 = sat(-(a0x * r.e0x + a0y * r.e0y) * r.il0);
-    const float t1 = sat(-(a1x * r.e1x + a1y * r.e1y) * r.il1);
-    const float t2 = sat(-(a2x * r.e2x + a2y * r.e2y) * r.il2);
+    const float t0 = SIL ? sat(a0x * r.iz0 + a0y * r.iz1) : sat(-(a0x * r.e0x + a0y * r.e0y) * r.il0);
+    const float t1 = SIL ? sat(a1x * r.iz2 + a1y * r.q0) : sat(-(a1x * r.e1x + a1y * r.e1y) * r.il1);
+    const float t2 = SIL ? sat(a2x * r.q1 + a2y * r.q2) : sat(-(a2x * r.e2x + a2y * r.e2y) * r.il2);
     const float d0x = fmaf(t0, r.e0x, a0x), d0y = fmaf(t0, r.e0y, a0y);
     const float d1x = fmaf(t1, r.e1x, a1x), d1y = fmaf(t1, r.e1y, a1y);
     const float d2x = fmaf(t2, r.e2x, a2x), d2y = fmaf(t2, r.e2y, a2y);
@@ -319,9 +323,9 @@ __device__ inline float pair_one_minus_D(const FaceRec &r, const Pixel &px, cons
     const float a0x = LO ? (r.p0x - xp) - px.xl : r.p0x - xp, a0y = LO ? (r.p0y - yp) - px.yl : r.p0y - yp;
     const float a1x = LO ? (r.p1x - xp) - px.xl : r.p1x - xp, a1y = LO ? (r.p1y - yp) - px.yl : r.p1y - yp;
     const float a2x = LO ? (r.p2x - xp) - px.xl : r.p2x - xp, a2y = LO ? (r.p2y - yp) - px.yl : r.p2y - yp;
-    const float t0 = sat(-(a0x * r.e0x + a0y * r.e0y) * r.il0);
-    const float t1 = sat(-(a1x * r.e1x + a1y * r.e1y) * r.il1);
-    const float t2 = sat(-(a2x * r.e2x + a2y * r.e2y) * r.il2);
+    const float t0 = sat(a0x * r.iz0 + a0y * r.iz1);       // a silhouette record: see FaceRec
+    const float t1 = sat(a1x * r.iz2 + a1y * r.q0);
+    const float t2 = sat(a2x * r.q1 + a2y * r.q2);
     const float d0x = fmaf(t0, r.e0x, a0x), d0y = fmaf(t0, r.e0y, a0y);
     const float d1x = fmaf(t1, r.e1x, a1x), d1y = fmaf(t1, r.e1y, a1y);
     const float d2x = fmaf(t2, r.e2x, a2x), d2y = fmaf(t2, r.e2y, a2y);
@@ -455,12 +459,17 @@ __device__ inline void setup_face(const DevParams &P, int gid, float x0, float y
     r[1] = make_float4(x2, y2, e0x, e0y);
     r[2] = make_float4(e1x, e1y, e2x, e2y);
     const float inv_det = 1.f / det;
-    r[3] = make_float4(l0 > 0.f ? 1.f / l0 : 0.f, l1 > 0.f ? 1.f / l1 : 0.f,
-                       l2 > 0.f ? 1.f / l2 : 0.f, inv_det);
+    const float il0 = l0 > 0.f ? 1.f / l0 : 0.f, il1 = l1 > 0.f ? 1.f / l1 : 0.f, il2 = l2 > 0.f ? 1.f / l2 : 0.f;
+    r[3] = make_float4(il0, il1, il2, inv_det);
     r[4] = make_float4(e0x * inv_det, e0y * inv_det, e1x * inv_det, e1y * inv_det);
-    r[5] = make_float4(iz0, iz1, iz2, (z0 - zref) * iz0);
-    r[6] = make_float4((z1 - zref) * iz1, (z2 - zref) * iz2,
-                       __int_as_float(raw_det < 0.f ? 1 : 0), zref);
+    if (P.mode == SV3D_TEX_NONE) {              // silhouettes: -e_k / |e_k|^2 where the depths would be
+        r[5] = make_float4(-e0x * il0, -e0y * il0, -e1x * il1, -e1y * il1);
+        r[6] = make_float4(-e2x * il2, -e2y * il2, __int_as_float(raw_det < 0.f ? 1 : 0), zref);
+    } else {
+        r[5] = make_float4(iz0, iz1, iz2, (z0 - zref) * iz0);
+        r[6] = make_float4((z1 - zref) * iz1, (z2 - zref) * iz2,
+                           __int_as_float(raw_det < 0.f ? 1 : 0), zref);
+    }
     r[7] = make_float4(__uint_as_float(box.x), __uint_as_float(box.y), e2x * inv_det, e2y * inv_det);
     pbox[gid] = box;
     if (q) {
@@ -907,7 +916,7 @@ __attribute__((amdgpu_waves_per_eu(MODE == SV3D_TEX_VERTEX8 ? 7 : 8))) void rast
 #endif
                     continue;
                 }
-                const PairGeom g = pair_geom<LO>(r, px, P);
+                const PairGeom g = pair_geom<LO, MODE == SV3D_TEX_NONE>(r, px, P);
                 A *= g.omD;
 #ifdef SV3D_TRACE
                 ++trace_visits;
@@ -2001,7 +2010,7 @@ __global__ __launch_bounds__(kThreads) void raster_backward_kernel(
 
         Pixel px;
         px.x = xp; px.y = yp; px.xl = in.xl; px.yl = in.yl;
-        PairGeom g = pair_geom<LO>(r, px, P);
+        PairGeom g = pair_geom<LO, MODE == SV3D_TEX_NONE>(r, px, P);
         const bool act = valid && g.act;
         // dL/dx, x = +-d2/sigma, through alpha
         float gx = act ? P0 * (MODE == SV3D_TEX_NONE ? g.D_any : g.D) : 0.f;
