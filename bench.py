@@ -248,9 +248,13 @@ def configs_leg(device, ev):
                             ("silhouette_batch_64", 64, dict(subdivide=3, mode="none", sigma=1e-4, alpha_only=True)),
                             ("silhouette_batch_512", 512, dict(subdivide=3, mode="none", sigma=1e-4, alpha_only=True))):
         case = RasterCase(device, batch, 256, gamma=1e-4, **kw)
-        for _ in range(5):
-            case.step()
-        torch.cuda.synchronize()
+        # 80 ms of the same work first: the card's clocks fall while the host builds the next case
+        # and only come back after tens of milliseconds (the headline's pre-roll, for every case)
+        t_pre = time.perf_counter()
+        while (time.perf_counter() - t_pre) < 0.08:
+            for _ in range(8):
+                case.step()
+            torch.cuda.synchronize()
         n = 20
         t0 = time.perf_counter()
         for _ in range(n):
@@ -291,8 +295,11 @@ def configs_leg(device, ev):
                                           stream), "chamfer backward")
 
     def timed(fn, iters=20):
-        for _ in range(3):
-            fn()
+        t_pre = time.perf_counter()
+        while (time.perf_counter() - t_pre) < 0.05:          # clocks up first
+            for _ in range(4):
+                fn()
+            torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(iters):
@@ -478,8 +485,12 @@ def chamfer_leg(device):
         def fwd():
             L.check(lib.sv3d_chamfer_forward(vp(a), vp(b), B, N, N, vp(d1), vp(d2), vp(i1), vp(i2), stream), "chamfer")
 
-        for _ in range(5):
-            fwd()
+        # warm-up long enough for the card's clocks to come back up (see the headline's pre-roll)
+        t_pre = time.perf_counter()
+        while (time.perf_counter() - t_pre) < 0.05:
+            for _ in range(16):
+                fwd()
+            torch.cuda.synchronize()
         iters = 50
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
