@@ -2541,7 +2541,12 @@ int raster_backward_impl(const sv3d_raster_params *p, const float *textures, con
     // Interval enumeration once a face covers enough pixels for it to pay: the expected box is a
     // few times S^2 / F pixels (measured with 1280 faces: 320^2 -8 %, 384^2 -6..12 %, 512^2
     // -13..28 %, but 256^2 +2..3 %; 5120 faces: 1024^2 -15 %, 512^2 +7 %; 320 faces at 256^2 -11 %)
-    const bool spans = p->backward_enumeration == SV3D_BWD_AUTO ? (long)d.S * d.S >= 64L * d.F
+    // The colour modes' steps are three times as long as the silhouette's, so the enumeration's own
+    // cost weighs a third as much: they gain from 24 pixels per face on (5120 faces at 512^2: surface
+    // -7 %, vertex colours -13 %, eight channels -15 %; 1280 faces at 256^2, 64 images: -5..7 %; 5120
+    // faces at 384^2: -2.5 %; 8 images at 256^2: no change).
+    const long pixels_per_face_min = d.mode == SV3D_TEX_NONE ? 64L : 24L;
+    const bool spans = p->backward_enumeration == SV3D_BWD_AUTO ? (long)d.S * d.S >= pixels_per_face_min * d.F
                                                                 : p->backward_enumeration == SV3D_BWD_INTERVALS;
 #define SV3D_BWD_CASE(M, LO_, H_, SP_)                                                                  \
     hipLaunchKernelGGL((raster_backward_kernel<M, LO_, H_, SP_>), fgrid, block, lds, s, rec, d.B * d.F,  \

@@ -35,6 +35,13 @@ CONFIGS = {
     "ref_mask_b3": (3, 256, True, 3, 1e-5, "none", 1),
     "ref_mask_b2": (2, 256, True, 3, 1e-5, "none", 1),
     "hd_mask_b2": (2, 256, True, 4, 1e-5, "none", 1),         # 5120 faces in a small launch
+    # colour modes at 51 and 26 raster pixels per face: where the backward's row intervals start to pay
+    "c2b64_rgb": (64, 256, False, 3, 1e-4, "surface", 6),
+    "c2b64_vert": (64, 256, False, 3, 1e-4, "vertex", 1),
+    "hd_vert": (64, 256, True, 4, 1e-5, "vertex", 1),
+    "hd_vert8": (64, 256, True, 4, 1e-5, "vertex8", 1),
+    "hd_rgb_s384": (64, 192, True, 4, 1e-5, "surface", 6),
+    "c2b64_rgb_sharp": (64, 256, False, 3, 1e-5, "surface", 6),
     "ref_rgb_b2": (2, 256, True, 3, 1e-5, "surface", 6),
     "s128_b32": (32, 128, False, 3, 1e-4, "none", 1),
     "s64_b64": (64, 64, False, 2, 1e-4, "none", 1),
