@@ -57,6 +57,9 @@ constexpr int kTile = 16;         // tile side in raster pixels
 #ifndef SV3D_SPLIT_MAX_TILES
 #define SV3D_SPLIT_MAX_TILES 2048               // two waves per block up to this many tiles per launch
 #endif
+#ifndef SV3D_SPLIT_MAX_TILES_COLOUR
+#define SV3D_SPLIT_MAX_TILES_COLOUR 3072        // ... in the colour modes
+#endif
 #ifndef SV3D_DIRECT_BOXES
 #define SV3D_DIRECT_BOXES 1
 #endif
@@ -2417,7 +2420,9 @@ int raster_forward_impl(const sv3d_raster_params *p, const float *face_vertices,
     const ForwardRoute route = forward_route(d, mesh != nullptr);
     const bool fused = route.fused, tiled = route.tiled, blists = route.blists, coarse = route.coarse;
     // two waves per block while the grid is small enough that single waves set the kernel's span
-    const bool split = (long)tiles * tiles * d.B <= SV3D_SPLIT_MAX_TILES;      // measured: 12 and 16 images of 256^2 are faster unsplit
+    // (measured: silhouettes of 12 and 16 images of 256^2 are faster unsplit; the colour modes, with
+    // their longer visits, still gain at 12 images -- forward -13 % -- and lose at 16)
+    const bool split = (long)tiles * tiles * d.B <= (d.mode == SV3D_TEX_NONE ? SV3D_SPLIT_MAX_TILES : SV3D_SPLIT_MAX_TILES_COLOUR);
     // group boxes are read by the large launches without coarse bins or per-tile lists only
     uint2 *gbox_setup = (!coarse && !tiled && !(SV3D_DIRECT_BOXES && split)) ? gbox : nullptr;
     int *tcount = nullptr;

@@ -36,6 +36,9 @@ CONFIGS = {
     "ref_mask_b2": (2, 256, True, 3, 1e-5, "none", 1),
     "hd_mask_b2": (2, 256, True, 4, 1e-5, "none", 1),         # 5120 faces in a small launch
     # colour modes at 51 and 26 raster pixels per face: where the backward's row intervals start to pay
+    "c2_rgb_b16": (16, 256, False, 3, 1e-4, "surface", 6),
+    "c2_rgb_b24": (24, 256, False, 3, 1e-4, "surface", 6),
+    "c2_vert_b16": (16, 256, False, 3, 1e-4, "vertex", 1),
     "c2b64_rgb": (64, 256, False, 3, 1e-4, "surface", 6),
     "c2b64_vert": (64, 256, False, 3, 1e-4, "vertex", 1),
     "hd_vert": (64, 256, True, 4, 1e-5, "vertex", 1),
