@@ -1626,14 +1626,17 @@ __device__ inline void merge_texel_step(int &tid, float &g0, float &g1, float &g
     const bool taker = (lane & BIT) == 0;
     const int up = __builtin_amdgcn_update_dpp(-1, tid, TAKE, 0xf, 0xf, false);
     const int dn = TAKE == GIVE ? up : __builtin_amdgcn_update_dpp(-1, tid, GIVE, 0xf, 0xf, false);
-    const float p0 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(g0), TAKE, 0xf, 0xf, false));
-    const float p1 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(g1), TAKE, 0xf, 0xf, false));
-    const float p2 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(g2), TAKE, 0xf, 0xf, false));
+    // (a source lane outside the row reads 0: with that the partner's value can ride on the
+    // multiply-add itself as its cross-lane operand, instead of a move of its own)
+    const float p0 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(g0), TAKE, 0xf, 0xf, true));
+    const float p1 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(g1), TAKE, 0xf, 0xf, true));
+    const float p2 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(g2), TAKE, 0xf, 0xf, true));
     const bool take = taker && up == tid;
     const bool give = !taker && dn == tid;
-    g0 += take ? p0 : 0.f;
-    g1 += take ? p1 : 0.f;
-    g2 += take ? p2 : 0.f;
+    const float takef = take ? 1.f : 0.f;
+    g0 = fmaf(p0, takef, g0);
+    g1 = fmaf(p1, takef, g1);
+    g2 = fmaf(p2, takef, g2);
     tid = give ? -2 - lane : tid;
 }
 
@@ -2097,7 +2100,9 @@ __global__ __launch_bounds__(kThreads) void raster_backward_kernel(
                 if (ttid >= 0) {
                     // the table by the lane's group of eight as well as its place in it: whole
                     // groups mostly end up in their first lane
-                    float *slot = s_tex + ((((lane >> 3) + lane) & (ncopy - 1)) * Ts + ttid) * 3;
+                    // (24-bit index arithmetic: the 32-bit product would be a quarter-rate instruction)
+                    const unsigned table = (unsigned)(((lane >> 3) + lane) & (ncopy - 1));
+                    float *slot = s_tex + __umul24(__umul24(table, (unsigned)Ts) + (unsigned)ttid, 3u);
                     atomicAdd(slot + 0, tg0);
                     atomicAdd(slot + 1, tg1);
                     atomicAdd(slot + 2, tg2);
