@@ -238,7 +238,9 @@ def test_colour_launch_whose_tile_lists_overflow():
     (12, 256, False, 3, 1e-4),      # 3072 tiles of a mesh with five faces per tile: still two waves per block
     (3, 256, True, 3, 1e-5),        # 3072 tiles, one wave per block
     (4, 200, False, 3, 3e-5),       # partial tiles at the border, pixel centres fp32 cannot hold exactly
-    (1, 256, True, 4, 1e-5),        # 5120 faces: the list builders stage them 1024 at a time
+    (1, 256, True, 4, 1e-5),        # 5120 faces: the list builders stage them 2048 at a time
+    (6, 256, False, 3, 1e-5),       # the sharpest sigma on the coarsest raster the tile-relative records serve
+    (2, 128, False, 2, 1e-5),       # ... and beyond it (sqrt(log2 e / sigma) * 16 / S = 47: still served)
 ])
 def test_small_silhouette_launches_with_setup_and_lists_in_one_kernel(B, img, aa, sub, sigma):
     """Launches of at most 4096 tiles that come with face_vertices: one kernel does the setup and
