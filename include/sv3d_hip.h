@@ -91,8 +91,13 @@ const char *sv3d_strerror(int status);
 int sv3d_abi_version(void);
 
 /* Byte sizes of the buffers the rasterizer calls need:
- *   face_rec_bytes    per-face setup records, pixel boxes, face-group boxes (and, for meshes
- *                     from 2048 faces, coarse-bin face lists) written by forward, read by backward
+ *   face_rec_bytes    per-face setup records, pixel boxes, face-group boxes and what the forward
+ *                     keeps per tile or bin for the configuration (coarse-bin face lists for
+ *                     meshes from 2048 faces; per-tile face lists, and for silhouettes oriented
+ *                     edge records, where the forward takes lists): written by forward, the
+ *                     per-face part read by backward.  Opaque: its layout may change with the
+ *                     parameters and between versions of the library, so forward and backward
+ *                     of one call pair must come from one library and one parameter block.
  *   pixel_saved_bytes per-raster-pixel aggregates written by forward, read by backward
  *   backward_ws_bytes scratch for backward; always 0 (the backward folds its inputs on
  *                     the fly), kept so that callers sized by this query stay valid;
