@@ -75,7 +75,7 @@ constexpr int kTile = 16;         // tile side in raster pixels
 #ifndef SV3D_EARLY_EXIT
 #define SV3D_EARLY_EXIT 1
 #endif
-// per-tile face lists (large silhouette launches, see raster_tile_lists_kernel)
+// per-tile face lists (see raster_tile_lists_kernel and raster_setup_lists_kernel)
 #ifndef SV3D_TILED
 #define SV3D_TILED 1
 #endif
@@ -101,7 +101,7 @@ constexpr int kTile = 16;         // tile side in raster pixels
 #define SV3D_BINNING_LISTS_MIN_TILES 4096           // other launches above this many tiles: lists instead of binning
 #endif
 #ifndef SV3D_TILED_MIN_TILES
-#define SV3D_TILED_MIN_TILES 4096                   // launches above this many tiles take the lists
+#define SV3D_TILED_MIN_TILES 4096                   // silhouette launches above this many tiles: lists from a kernel of their own
 #endif
 constexpr int kListCap = SV3D_LIST_CAP;   // faces staged in LDS at a time (128 B each)
 constexpr int kRecPad4 = kRec4 + 1;       // LDS record stride (144 B): lane-strided reads are conflict free
@@ -1185,9 +1185,13 @@ __attribute__((amdgpu_waves_per_eu(MODE == SV3D_TEX_VERTEX8 ? 7 : 8))) void rast
 
 
 // ------------------------------------------------------------------------------------
-// per-tile face lists (large silhouette launches)
+// per-tile face lists
 // ------------------------------------------------------------------------------------
-// For large launches the per-tile work of the forward that is not fragment arithmetic -- every tile
+// Which launches take them: silhouettes of at most SV3D_TILED_FUSED_MAX_TILES tiles that come with
+// face_vertices (lists from raster_setup_lists_kernel) and of more than SV3D_TILED_MIN_TILES (lists
+// from raster_tile_lists_kernel), both into raster_forward_tiled_kernel; every other launch of more
+// than SV3D_BINNING_LISTS_MIN_TILES tiles, into the general forward kernel in place of its binning.
+// In a launch the per-tile work of the forward that is not fragment arithmetic -- every tile
 // testing the boxes of its image's faces, numbering its hits, copying their 128-byte records and
 // testing each against its four blocks -- is nearly half of the kernel's instructions.  Here a
 // kernel of its own makes, per tile, the ordered list of the faces whose pixel box touches it
