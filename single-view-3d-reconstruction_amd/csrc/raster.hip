@@ -1438,8 +1438,12 @@ __device__ inline float tile_visit(const float4 r0, const float4 r1, const float
     const float o2 = fmaxf(fmaxf(-(q2 + r3.x), q2 + r3.y), 0.f);
     const float dd = fminf(fmaf(o0, o0, h0 * h0), fminf(fmaf(o1, o1, h1 * h1), fmaf(o2, o2, h2 * h2)));
     const bool inside = fminf(h0, fminf(h1, h2)) > 0.f;
-    // 1 - D = 1 / (1 + exp(+-d2 / sigma)), + inside: see pair_one_minus_D
-    return rcp(1.f + ex2(inside ? dd : -dd));
+    // 1 - D = 1 / (1 + exp(+-d2 / sigma)), + inside: see pair_one_minus_D.  The DENOMINATOR is
+    // returned: a pixel's product of (1 - D) is the reciprocal of the product of these, so the
+    // reciprocal (a quarter-rate instruction) is taken once per pixel instead of once per visit.
+    // An overflowing product is +inf and its reciprocal 0, which is what the product of the
+    // factors would have underflowed to; every denominator is >= 1, so inf never meets 0.
+    return 1.f + ex2(inside ? dd : -dd);
 }
 
 template <int NB, int HALVES>
@@ -1469,7 +1473,7 @@ __global__ __launch_bounds__(kThreads / NB * HALVES) void raster_forward_tiled_k
     const int bc0 = NB == 2 ? 0 : (wave & 1) * 8, br0 = NB == 2 ? wave * 8 : (wave >> 1) * 8;
     const int lc = bc0 + (quad & 3) * 2 + (sub & 1), lr = br0 + (quad >> 2) * 2 + (sub >> 1);
     const int col = tile_c0 + lc, row = tile_r0 + lr;
-    float A0 = 1.f, A1 = 1.f;
+    float A0 = 1.f, A1 = 1.f;                   // products of the visits' denominators, see tile_visit
     if (n_list > 0) {                                                   // uniform over the workgroup
         // pixel centres relative to the tile centre: odd multiples of 1/S, exact when S is a power of two
         // (otherwise rounded by 6e-8 of at most 15/S: a thirtieth of what rounding the centre itself costs)
@@ -1578,7 +1582,7 @@ __global__ __launch_bounds__(kThreads / NB * HALVES) void raster_forward_tiled_k
     float *alpha_b = rgba_b + (size_t)(planes - 1) * plane;
 #pragma unroll
     for (int side = 0; side < NB; ++side) {
-        const float A = fminf(side ? A1 : A0, 1.f);
+        const float A = fminf(rcp(side ? A1 : A0), 1.f);
         const float alpha = 1.f - A;
         const int c = col + 8 * side;
         const bool inimg = c < S && row < S;
