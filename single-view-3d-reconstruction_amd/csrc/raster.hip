@@ -1204,16 +1204,17 @@ __attribute__((amdgpu_waves_per_eu(MODE == SV3D_TEX_VERTEX8 ? 7 : 8))) void rast
 // Tile-relative record (16 floats).  With c = sqrt(log2(e) / sigma), for each edge k taken from A
 // to B so that the face's inside is on its left (the two are swapped for faces of the other
 // orientation), u = its unit direction, and a pixel centre x = tile centre + o:
-//     s  = c u.(x - A) = S0 + Sx ox + Sy oy       along the edge from A,   (Sx, Sy) = c u
-//     s2 = c u.(x - B) = S1 + Sx ox + Sy oy       along the edge from B  (= s - c |e|, but formed
-//                                                 from B itself: no cancellation near B)
-//     h  = c n.(x - A) = H0 - Sy ox + Sx oy       across the edge, > 0 inside,  n = (-uy, ux)
-// The squared distance to the segment, times log2(e)/sigma, is h^2 + max(-s, s2, 0)^2: 9
-// multiply-adds and selects per edge where the point-to-segment form on absolute coordinates takes
-// 14, and the pixel is inside the face iff min(h0, h1, h2) > 0.  o is exact in fp32 (a small odd
-// multiple of 1/S), and S0, S1, H0 come from centre - A formed with one rounding, so the 1/sigma
-// slope acts on numbers no larger than the tile.
-// Layout: [Sx0 Sy0 S00 S10] [H00 Sx1 Sy1 S01] [S11 H01 Sx2 Sy2] [S02 S12 H02 box], box = the
+//     s = c u.(x - A)                              along the edge from A,   (Sx, Sy) = c u
+//     h = c n.(x - A) = H0 - Sy ox + Sx oy         across the edge, > 0 inside,  n = (-uy, ux)
+// The squared distance to the segment, times log2(e)/sigma, is h^2 + (how far s lies outside
+// [0, c |e|])^2, and the pixel is inside the face iff min(h0, h1, h2) > 0.  The interval is stored
+// by its middle and half length, and cut to what the tile can reach (make_tile_record):
+//     s - middle = C + Sx ox + Sy oy,    outside by max(|s - middle| - L, 0)
+// eight multiply-adds, subtractions and maxima per edge where the point-to-segment form on absolute
+// coordinates takes 14.  o is exact in fp32 (a small odd multiple of 1/S), and C, L, H0 come from
+// centre - A and centre - B formed with one rounding each, so the 1/sigma slope acts on numbers no
+// larger than the tile.
+// Layout: [Sx0 Sy0 C0 L0] [H00 Sx1 Sy1 C1] [L1 H01 Sx2 Sy2] [C2 L2 H02 box], box = the
 // face's pixel box inside the tile, four 4-bit fields (col0, col1, row0, row1; 0..15).
 constexpr int kTileCap = 128;                   // records per tile slot
 static_assert(kTileCap == kListCap, "a tile's list fills one window of the general forward kernel");
@@ -1406,11 +1407,30 @@ __device__ inline void make_tile_record(const float4 e0, const float4 e1, const 
                           (unsigned)min(max(a0 - tc0, 0), 15) | ((unsigned)min(max(a1 - tc0, 0), 15) << 4) |
                           ((unsigned)min(max(b0 - tr0, 0), 15) << 8) | ((unsigned)min(max(b1 - tr0, 0), 15) << 12);
     // per edge: Sx, Sy, S0 = S.(centre - A), S1 = S.(centre - B), H0 = n.(centre - A), n = (-Sy, Sx)
-    o[0] = make_float4(e0.z, e0.w, fmaf(e0.z, d0x, e0.w * d0y), fmaf(e0.z, d1x, e0.w * d1y));
-    o[1] = make_float4(fmaf(-e0.w, d0x, e0.z * d0y), e1.z, e1.w, fmaf(e1.z, d1x, e1.w * d1y));
-    o[2] = make_float4(fmaf(e1.z, d2x, e1.w * d2y), fmaf(-e1.w, d1x, e1.z * d1y), e2.z, e2.w);
-    o[3] = make_float4(fmaf(e2.z, d2x, e2.w * d2y), fmaf(e2.z, d0x, e2.w * d0y), fmaf(-e2.w, d2x, e2.z * d2y),
-                       __uint_as_float(bits));
+    // per edge: Sx, Sy, C, L, H0 = n.(centre - A).  With s = S.(x - A) the pixel's place along the
+    // edge, the part of its distance that lies along the edge is how far s is outside [0, |S.(B - A)|].
+    // Over the tile s stays within R = (|Sx| + |Sy|) 15/S of its value at the centre, so an end of the
+    // interval farther away than that may be moved up to that reach without changing any pixel of
+    // the tile; the interval is then [centre value - da, centre value - db] with da, db below, both
+    // small numbers formed from S.(centre - A) and S.(centre - B) -- each exact near its own end --
+    // and the pixel's distance outside it is max(|s - middle| - L, 0): C = (da + db) / 2 puts the
+    // middle at the origin, L = (da - db) / 2.
+    const float reach = 15.f * inv_S;
+    auto along = [&](float Sx, float Sy, float ax, float ay, float bx, float by, float &C, float &L) {
+        const float R = (fabsf(Sx) + fabsf(Sy)) * reach;
+        const float SA = fmaf(Sx, ax, Sy * ay), SB = fmaf(Sx, bx, Sy * by);
+        const float da = fminf(SA, fmaxf(R, SB)), db = fminf(SA, fmaxf(-R, SB));
+        C = 0.5f * (da + db);
+        L = 0.5f * (da - db);
+    };
+    float C0, L0, C1, L1, C2, L2;
+    along(e0.z, e0.w, d0x, d0y, d1x, d1y, C0, L0);
+    along(e1.z, e1.w, d1x, d1y, d2x, d2y, C1, L1);
+    along(e2.z, e2.w, d2x, d2y, d0x, d0y, C2, L2);
+    o[0] = make_float4(e0.z, e0.w, C0, L0);
+    o[1] = make_float4(fmaf(-e0.w, d0x, e0.z * d0y), e1.z, e1.w, C1);
+    o[2] = make_float4(L1, fmaf(-e1.w, d1x, e1.z * d1y), e2.z, e2.w);
+    o[3] = make_float4(C2, L2, fmaf(-e2.w, d2x, e2.z * d2y), __uint_as_float(bits));
 }
 
 // The silhouette forward over per-tile lists: one workgroup per 16x16 tile.  A tile without faces
@@ -1429,21 +1449,20 @@ __device__ inline void make_tile_record(const float4 e0, const float4 e1, const 
 __device__ inline float tile_visit(const float4 r0, const float4 r1, const float4 r2, const float4 r3, float ox, float oy)
 {
     // along each edge (shared part), across it, beyond its ends
-    const float q0 = fmaf(r0.x, ox, r0.y * oy), q1 = fmaf(r1.y, ox, r1.z * oy), q2 = fmaf(r2.z, ox, r2.w * oy);
+    const float c0 = fmaf(r0.x, ox, fmaf(r0.y, oy, r0.z)), c1 = fmaf(r1.y, ox, fmaf(r1.z, oy, r1.w)),
+                c2 = fmaf(r2.z, ox, fmaf(r2.w, oy, r3.x));
     const float h0 = fmaf(-r0.y, ox, fmaf(r0.x, oy, r1.x));
     const float h1 = fmaf(-r1.z, ox, fmaf(r1.y, oy, r2.y));
     const float h2 = fmaf(-r2.w, ox, fmaf(r2.z, oy, r3.z));
-    const float o0 = fmaxf(fmaxf(-(q0 + r0.z), q0 + r0.w), 0.f);
-    const float o1 = fmaxf(fmaxf(-(q1 + r1.w), q1 + r2.x), 0.f);
-    const float o2 = fmaxf(fmaxf(-(q2 + r3.x), q2 + r3.y), 0.f);
+    const float o0 = fmaxf(fabsf(c0) - r0.w, 0.f), o1 = fmaxf(fabsf(c1) - r2.x, 0.f), o2 = fmaxf(fabsf(c2) - r3.y, 0.f);
     const float dd = fminf(fmaf(o0, o0, h0 * h0), fminf(fmaf(o1, o1, h1 * h1), fmaf(o2, o2, h2 * h2)));
-    const bool inside = fminf(h0, fminf(h1, h2)) > 0.f;
     // 1 - D = 1 / (1 + exp(+-d2 / sigma)), + inside: see pair_one_minus_D.  The DENOMINATOR is
     // returned: a pixel's product of (1 - D) is the reciprocal of the product of these, so the
     // reciprocal (a quarter-rate instruction) is taken once per pixel instead of once per visit.
     // An overflowing product is +inf and its reciprocal 0, which is what the product of the
     // factors would have underflowed to; every denominator is >= 1, so inf never meets 0.
-    return 1.f + ex2(inside ? dd : -dd);
+    // (the sign of the smallest h put on dd: one bit-field insert; on a boundary, where that h is zero, dd is zero too)
+    return 1.f + ex2(copysignf(dd, fminf(h0, fminf(h1, h2))));
 }
 
 template <int NB, int HALVES>
