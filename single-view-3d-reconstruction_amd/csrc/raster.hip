@@ -249,6 +249,7 @@ struct PairGeom {
     float w0, w1, w2;             // barycentric coordinates of the pixel
     bool k0, k1, k2;              // which edge is nearest (first wins ties)
     bool inside, act;
+    float wmin;                   // min(w0, w1, w2): > 0 inside
     float D, omD;                 // sigmoid fragment and 1 - D
     float D_any;                  // the fragment before the activity test (D where act, else arbitrary)
 };
@@ -301,12 +302,16 @@ __device__ inline PairGeom pair_geom(const FaceRec &r, const Pixel &px, const De
     g.t = g.k0 ? t0 : (g.k1 ? t1 : t2);
     g.dx = g.k0 ? d0x : (g.k1 ? d1x : d2x);
     g.dy = g.k0 ? d0y : (g.k1 ? d1y : d2y);
-    g.inside = fminf(g.w0, fminf(g.w1, g.w2)) > 0.f;              // one v_min3 and one compare
+    g.wmin = fminf(g.w0, fminf(g.w1, g.w2));                      // one v_min3
+    g.inside = g.wmin > 0.f;
+    // The squared distance with the sign of wmin, + inside: one bit-field insert.  (Where wmin is
+    // zero -- on the boundary, counted as outside -- the distance is zero as well.)
+    const float xs = copysignf(g.d2, g.wmin);
     // A pixel outside the face's cull box (bbox widened by sqrt(threshold)) is farther than
     // sqrt(threshold) from the triangle, so the distance test alone implements both culls.
-    g.act = g.inside || g.d2 < P.threshold;
+    g.act = xs > -P.threshold;
     // exp(-x) with x = +-d2/sigma; D = 1/(1+exp(-x)); 1-D = exp(-x) D (no cancellation)
-    const float e = ex2((g.inside ? g.d2 : -g.d2) * P.neg_l2e_over_sigma);
+    const float e = ex2(xs * P.neg_l2e_over_sigma);
     const float D = rcp(1.f + e);
     g.D_any = D;
     g.D = g.act ? D : 0.f;
@@ -1829,8 +1834,8 @@ __global__ __launch_bounds__(kThreads) void raster_backward_kernel(
     constexpr int kStride = 64 * HALVES;        // pixel numbers between two steps of one wave
     const int rows_live = npix > 0 ? bh : 0;
     float adv_x = 0.f, adv_y = 0.f, rx_f = 0.f, ry_f = 0.f;
-    // without anti-aliasing the lane's pixel index is carried along with its position: a step adds
-    // one of two wave-uniform increments (with or without a row wrap)
+    // without anti-aliasing the lane's pixel index (as a byte offset: times four) is carried along with
+    // its position: a step adds one of two wave-uniform increments (with or without a row wrap)
     int pix_run = 0, pix_adv = 0, pix_adv_wrap = 0;
     if (!SPANS) {
         const float inv_bw = bw > 0 ? rcp((float)bw) : 0.f;     // the fix-ups below absorb its last-bit error
@@ -1845,9 +1850,9 @@ __global__ __launch_bounds__(kThreads) void raster_backward_kernel(
         rx_f = fmaf(-ry_f, bw_f, lane0);
         if (rx_f < 0.f) { ry_f -= 1.f; rx_f += bw_f; }
         if (rx_f >= bw_f) { ry_f += 1.f; rx_f -= bw_f; }
-        pix_run = (row0 + (int)ry_f) * S + col0 + (int)rx_f;
-        pix_adv = (int)adv_y * S + (int)adv_x;
-        pix_adv_wrap = pix_adv + S - bw;
+        pix_run = ((row0 + (int)ry_f) * S + col0 + (int)rx_f) * 4;
+        pix_adv = ((int)adv_y * S + (int)adv_x) * 4;
+        pix_adv_wrap = pix_adv + (S - bw) * 4;
     }
 
     // Raw per-pixel inputs: the forward's saved aggregates and the incoming gradient.  They are
@@ -1862,8 +1867,8 @@ __global__ __launch_bounds__(kThreads) void raster_backward_kernel(
     };
     // per-pixel loads below take a wave-uniform base and a 32-bit byte offset (planes and the saved
     // array of one image stay far below 4 GB), which the hardware adds itself
-    auto at32 = [](const float *base, unsigned index) -> float {
-        return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(base) + index * 4u);
+    auto at32 = [](const float *base, unsigned index4) -> float {       // index4: four times the float's index
+        return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(base) + index4);
     };
     // SPANS, of the current 64 rows: inclusive prefix sum of the interval lengths, start << 12 | lo
     // per row, pixels in all, first row.  Otherwise span_total is the box's pixel count.
@@ -1871,7 +1876,7 @@ __global__ __launch_bounds__(kThreads) void raster_backward_kernel(
     auto fetch = [&](int base) {                    // inputs of pixel number base + lane
         PixIn in;
         float cx, cy;
-        unsigned pix = 0, gpix = 0;
+        unsigned pix = 0, gpix = 0;             // four times the pixel's index in the raster / the output image
         if (SPANS) {
             const int pnum = base + lane;
             in.valid = pnum < span_total;
@@ -1920,7 +1925,7 @@ __global__ __launch_bounds__(kThreads) void raster_backward_kernel(
             pix = gpix = in.valid ? (unsigned)pix_run : 0u;
             if (aa_ == 2) {                     // wave-uniform
                 const unsigned prow = (unsigned)(row0 + (int)cy), pcol = (unsigned)(col0 + (int)cx);
-                gpix = in.valid ? __umul24(prow >> 1, (unsigned)H) + (pcol >> 1) : 0u;
+                gpix = in.valid ? (__umul24(prow >> 1, (unsigned)H) + (pcol >> 1)) << 2 : 0u;
             }
             // advance to the pixel kStride positions further
             rx_f += adv_x;
@@ -1941,8 +1946,8 @@ __global__ __launch_bounds__(kThreads) void raster_backward_kernel(
         if (SPANS) {
             const unsigned prow = (unsigned)(row0 + (int)cy), pcol = (unsigned)(col0 + (int)cx);
             // rows, columns and sizes are at most 4096: 24-bit multiplies (one v_mad_u32_u24 each)
-            pix = __umul24(prow, (unsigned)S) + pcol;
-            gpix = aa_ == 2 ? __umul24(prow >> 1, (unsigned)H) + (pcol >> 1) : pix;
+            pix = (__umul24(prow, (unsigned)S) + pcol) << 2;
+            gpix = aa_ == 2 ? (__umul24(prow >> 1, (unsigned)H) + (pcol >> 1)) << 2 : pix;
         }
         in.ssum = in.m = 0.f;
 #pragma unroll
@@ -1951,11 +1956,11 @@ __global__ __launch_bounds__(kThreads) void raster_backward_kernel(
         if (MODE == SV3D_TEX_NONE) {
             in.A = at32(saved_b, pix);
         } else if (NC == 3) {
-            const float2 *sp = reinterpret_cast<const float2 *>(reinterpret_cast<const char *>(saved_b) + pix * 24u);
+            const float2 *sp = reinterpret_cast<const float2 *>(reinterpret_cast<const char *>(saved_b) + pix * 6u);
             const float2 a0 = sp[0], a1 = sp[1], a2 = sp[2];
             in.A = a0.x; in.ssum = a0.y; in.m = a1.x; in.col[0] = a1.y; in.col[1] = a2.x; in.col[2] = a2.y;
         } else {
-            const float4 *sp = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(saved_b) + pix * 48u);
+            const float4 *sp = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(saved_b) + pix * 12u);
             const float4 a0 = sp[0], a1 = sp[1], a2 = sp[2];
             in.A = a0.x; in.ssum = a0.y; in.m = a0.z;
             const float cs[8] = {a0.w, a1.x, a1.y, a1.z, a1.w, a2.x, a2.y, a2.z};
@@ -2137,7 +2142,7 @@ __global__ __launch_bounds__(kThreads) void raster_backward_kernel(
             }
         }
         // through the distance: d2 = |foot - pixel|^2, foot = (1-t) p_k + t p_{k+1}
-        const float gd = gx * (g.inside ? dist_slope : -dist_slope);
+        const float gd = gx * copysignf(dist_slope, g.wmin);
         const float cA = gd * (1.f - g.t), cB = gd * g.t;
         const float f0 = g.k0 ? cA : (g.k2 ? cB : 0.f);
         const float f1 = g.k1 ? cA : (g.k0 ? cB : 0.f);
