@@ -1448,8 +1448,8 @@ __device__ inline void make_tile_record(const float4 e0, const float4 e1, const 
 // NB = 1: four waves, one block each.  NB = 2 (the largest launches): two waves, rows 0-7 and 8-15,
 // each wave's lanes holding one pixel of the left and one of the right block; a visit's record is
 // then read from LDS once for both blocks.  The four broadcast ds_read_b128 of a visit take 16
-// cycles of the CU's LDS array, which four SIMDs running one-block visits (70 cycles of VALU issue
-// each) keep 90 % busy: the LDS, not the VALU, bounds them.  (Fewer, longer waves: launches of fewer
+// cycles of the CU's LDS array, which four SIMDs running one-block visits (31 vector instructions,
+// 62 cycles of VALU issue each) keep fully busy: the LDS bounds them as much as the VALU does.  (Fewer, longer waves: launches of fewer
 // than some ten thousand tiles, bound by their longest waves, keep one block per wave.)
 __device__ inline float tile_visit(const float4 r0, const float4 r1, const float4 r2, const float4 r3, float ox, float oy)
 {
