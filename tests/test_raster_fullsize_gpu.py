@@ -83,9 +83,11 @@ def _raster_pixels(out_pix, img, aa):
     return torch.stack(sub, 1)
 
 
-def sampled_compare(name, fv, tex, img, aa, mode, n_out, check_images=None, fp32_floor=False, **kw):
+def sampled_compare(name, fv, tex, img, aa, mode, n_out, check_images=None, fp32_floor=False, grad_tol=None, **kw):
     """GPU forward + backward over the whole batch; oracle on `n_out` output pixels of every image
-    in `check_images` (default: all).  Returns the worst errors."""
+    in `check_images` (default: all).  Returns the worst errors.  `grad_tol`: bar of the vertex
+    gradient where the case is beyond what fp32 corner-relative arithmetic holds (the caller then
+    compares with the upstream arithmetic in fp32, `fp32_floor`)."""
     B, F = fv.shape[:2]
     S = img * (2 if aa else 1)
     channels = 9 if mode == "vertex8" else 4
@@ -149,8 +151,8 @@ def sampled_compare(name, fv, tex, img, aa, mode, n_out, check_images=None, fp32
         worst["fp32_upstream_p999_fv"] = elementwise_rel_err(x32.grad, xb.grad)
     _record(name, **worst)
     assert worst["unstable"] < 2e-2 and worst["sliver_faces"] <= 2 * len(check), worst
-    assert worst["img"] < TOL and worst["grad_fv"] < TOL and worst["grad_tex"] < TOL, worst
-    assert worst["p999_fv"] < P999_TOL and worst["p999_tex"] < P999_TOL, worst
+    assert worst["img"] < TOL and worst["grad_fv"] < (grad_tol or TOL) and worst["grad_tex"] < TOL, worst
+    assert worst["p999_fv"] < P999_TOL * (grad_tol or TOL) / TOL and worst["p999_tex"] < P999_TOL, worst
     return worst
 
 
@@ -250,6 +252,22 @@ def test_small_silhouette_launches_with_setup_and_lists_in_one_kernel(B, img, aa
     fv = camera_space_faces(verts, faces, B, seed=30 + B)
     sampled_compare("fused_lists_b%d_%d%s_sub%d" % (B, img, "aa" if aa else "", sub), fv, None, img, aa, "none",
                     256, check_images=sorted({0, B // 2, B - 1}), sigma=sigma)
+
+
+@pytest.mark.parametrize("B", [2, 5, 12])
+def test_tiled_forward_with_faces_many_tiles_long(B):
+    """An 80-face mesh on a 512^2 raster at sigma 1e-5: edges of a hundred pixels, six tiles long.  A
+    tile's record holds, per edge, the part of the edge's extent that the tile can reach, so its
+    numbers stay small however long the edge is; the sharpest sigma makes any lost bits show.
+    Two images: lists from the setup kernel; five: lists from their own kernel, one block per wave;
+    twelve: two blocks per wave."""
+    verts, faces = load_mesh(1)
+    fv = camera_space_faces(verts, faces, B, seed=40 + B)
+    w = sampled_compare("tiled_long_edges_512_b%d" % B, fv, None, 512, False, "none", 384,
+                        check_images=sorted({0, B // 2, B - 1}), fp32_floor=True, grad_tol=3e-5, sigma=1e-5)
+    # the image is what the tile records decide; the gradient of faces this long at this sigma is at
+    # the fp32 floor of any corner-relative form (the backward's), and below the upstream arithmetic's
+    assert w["img"] < 0.3 * TOL and w["grad_fv"] < w["fp32_upstream_grad_fv"], w
 
 
 def test_tiled_forward_on_a_raster_that_is_not_a_power_of_two():
