@@ -1488,8 +1488,15 @@ __global__ __launch_bounds__(kThreads / NB * HALVES) void raster_forward_tiled_k
     tile_position(blockIdx.y, blockIdx.z, tiles_x, SV3D_SPIRAL && HALVES == 2, tile_x, tile_y);
     const size_t tile = ((size_t)b * tiles_x + tile_y) * tiles_x + tile_x;
     // the list's ids are requested alongside its length, not behind it
+    SV3D_STAMP(0);
     const int my_id = (int)threadIdx.x < kTileCap ? (int)tlist[tile * kTileCap + threadIdx.x] : 0;
     const int n_list = tcount[tile];
+#ifdef SV3D_TRACE
+    if (threadIdx.x == 0 && SV3D_WG_ID < 4096) {
+        g_phase[SV3D_WG_ID * 8 + 1] = __builtin_amdgcn_s_memrealtime() + (unsigned long long)(my_id < 0 ? 1 : 0);
+        g_phase[SV3D_WG_ID * 8 + 7] = (unsigned long long)n_list;
+    }
+#endif
     const int S = P.S, F = num_faces;
     const int tile_c0 = tile_x * kTile, tile_r0 = tile_y * kTile;
     const int quad = lane >> 2, sub = lane & 3;
@@ -1512,6 +1519,7 @@ __global__ __launch_bounds__(kThreads / NB * HALVES) void raster_forward_tiled_k
 
         auto process_window = [&](int nw, bool last) {
             __syncthreads();
+            SV3D_STAMP(2);
             for (int j0 = 0; j0 < nw; j0 += 64) {
                 const int j = j0 + lane;
                 bool hit0 = false, hit1 = false;
@@ -1587,6 +1595,7 @@ __global__ __launch_bounds__(kThreads / NB * HALVES) void raster_forward_tiled_k
                 process_window(nw, f0 + kTileCap >= F);
             }
         }
+        SV3D_STAMP(3);
         if (HALVES == 2) {                      // n_list is uniform over the workgroup: every wave is here
             if (part == 1) s_half[wave * 64 + lane] = A0;
             __syncthreads();
@@ -1626,6 +1635,7 @@ __global__ __launch_bounds__(kThreads / NB * HALVES) void raster_forward_tiled_k
             if (!only_alpha) { rgba_b[ob] = P.bg0; rgba_b[ob + plane] = P.bg1; rgba_b[ob + 2 * plane] = P.bg2; }
         }
     }
+    SV3D_STAMP(4);
 }
 
 // ------------------------------------------------------------------------------------
