@@ -82,6 +82,9 @@ constexpr int kTile = 16;         // tile side in raster pixels
 #ifndef SV3D_TILED_TWO_BLOCKS_MIN_TILES
 #define SV3D_TILED_TWO_BLOCKS_MIN_TILES 12288   // two blocks per wave from this many tiles per launch
 #endif
+#ifndef SV3D_TILED_HALVES_TWO_BLOCKS_MIN_TILES
+#define SV3D_TILED_HALVES_TWO_BLOCKS_MIN_TILES 1536 // two waves per block: from this many tiles on they share two blocks
+#endif
 #ifndef SV3D_TILED_FUSED_MAX_TILES
 #define SV3D_TILED_FUSED_MAX_TILES 4096             // at most this many tiles: setup and lists in one launch
 #endif
@@ -89,7 +92,7 @@ constexpr int kTile = 16;         // tile side in raster pixels
 #define SV3D_TILED_HALVES_MAX_TILES 2048            // ... and two waves per block in the forward
 #endif
 #ifndef SV3D_TILED_HALVES_MAX_TILES_DENSE
-#define SV3D_TILED_HALVES_MAX_TILES_DENSE 3072      // the same for meshes of at least four faces per tile
+#define SV3D_TILED_HALVES_MAX_TILES_DENSE 7168      // the same for meshes of at least four faces per tile
 #endif
 #ifndef SV3D_TILED_MAX_FACES_PER_TILE
 #define SV3D_TILED_MAX_FACES_PER_TILE 8             // faces of the mesh per tile of an image, at most
@@ -1443,8 +1446,12 @@ __device__ inline void make_tile_record(const float4 e0, const float4 e1, const 
 // tile-relative records in LDS (one thread per face: ids, then the faces' records -- two trips to
 // memory -- and one barrier), and every wave tests the list against its 8x8 blocks lane-parallel
 // and walks its hits.
-// HALVES = 2 (NB = 1 only; the smallest launches, bound by their longest waves): eight waves, two per
-// block, which take the block's hits in turn and multiply their products together through LDS.
+// HALVES = 2 (small launches, bound by their longest waves): two waves per block -- or, with NB = 2,
+// per pair of blocks -- which take the hits in turn and multiply their products together through
+// LDS.  With NB = 1 that is eight waves per tile: 2048 tiles are then two rounds of what the chip
+// holds at once, and the four SIMDs' visits keep the CU's LDS as busy as themselves; with NB = 2,
+// four waves per tile, everything up to 2048 tiles is resident at once and a record is read once
+// for two blocks (measured: better from 1536 tiles on, -5..11 %; worse at 1024 and 1280).
 // NB = 1: four waves, one block each.  NB = 2 (the largest launches): two waves, rows 0-7 and 8-15,
 // each wave's lanes holding one pixel of the left and one of the right block; a visit's record is
 // then read from LDS once for both blocks.  The four broadcast ds_read_b128 of a visit take 16
@@ -1475,7 +1482,6 @@ __global__ __launch_bounds__(kThreads / NB * HALVES) void raster_forward_tiled_k
     const int *__restrict__ tcount, const unsigned short *__restrict__ tlist, const float4 *__restrict__ srec,
     const uint2 *__restrict__ pbox, int num_faces, float *__restrict__ rgba, float *__restrict__ saved, DevParams P)
 {
-    static_assert(HALVES == 1 || NB == 1, "two waves per block: one block per wave");
     __shared__ float4 s_trec[kTileCap * kTRecPad4];
     __shared__ float s_half[HALVES == 2 ? kThreads : 1];
     const int tiles_x = (P.S + kTile - 1) / kTile;
@@ -1545,11 +1551,13 @@ __global__ __launch_bounds__(kThreads / NB * HALVES) void raster_forward_tiled_k
                     }
                 }
                 unsigned long long mask0 = __ballot(hit0);
-                const unsigned long long mask1 = __ballot(hit1);
-                if (HALVES == 2) {              // the block's hits alternate between its two waves
-                    const bool mine = hit0 && (((hits_seen + __popcll(mask0 & lane_lt)) & 1) == part);
-                    hits_seen += __popcll(mask0);
-                    mask0 = __ballot(mine);
+                unsigned long long mask1 = __ballot(hit1);
+                if (HALVES == 2) {              // the hits (of either block) alternate between the two waves
+                    const unsigned long long any = mask0 | mask1;
+                    const bool mine = (hit0 || hit1) && (((hits_seen + __popcll(any & lane_lt)) & 1) == part);
+                    hits_seen += __popcll(any);
+                    mask0 = __ballot(mine && hit0);
+                    mask1 = __ballot(mine && hit1);
                 }
                 unsigned long long mask = mask0 | mask1;
                 while (mask) {
@@ -1597,10 +1605,14 @@ __global__ __launch_bounds__(kThreads / NB * HALVES) void raster_forward_tiled_k
         }
         SV3D_STAMP(3);
         if (HALVES == 2) {                      // n_list is uniform over the workgroup: every wave is here
-            if (part == 1) s_half[wave * 64 + lane] = A0;
+            if (part == 1) {
+                s_half[wave * 64 + lane] = A0;
+                if (NB == 2) s_half[(2 + wave) * 64 + lane] = A1;
+            }
             __syncthreads();
             if (part == 1) return;
             A0 *= s_half[wave * 64 + lane];
+            if (NB == 2) A1 *= s_half[(2 + wave) * 64 + lane];
         }
     } else if (HALVES == 2 && part == 1) {
         return;
@@ -2532,6 +2544,9 @@ int raster_forward_impl(const sv3d_raster_params *p, const float *face_vertices,
         for (int rep = 0; rep < repeats; ++rep) {
             if (ntiles >= SV3D_TILED_TWO_BLOCKS_MIN_TILES)
                 hipLaunchKernelGGL((raster_forward_tiled_kernel<2, 1>), tgrid, dim3(kThreads / 2), 0, s, tcount, tlist,
+                                   srec, pbox, d.F, rgba_out, saved, d);
+            else if (tiled_halves(d) && ntiles >= SV3D_TILED_HALVES_TWO_BLOCKS_MIN_TILES)
+                hipLaunchKernelGGL((raster_forward_tiled_kernel<2, 2>), tgrid, dim3(kThreads), 0, s, tcount, tlist,
                                    srec, pbox, d.F, rgba_out, saved, d);
             else if (tiled_halves(d))
                 hipLaunchKernelGGL((raster_forward_tiled_kernel<1, 2>), tgrid, dim3(kThreads * 2), 0, s, tcount, tlist,

@@ -270,6 +270,18 @@ def test_tiled_forward_with_faces_many_tiles_long(B):
     assert w["img"] < 0.3 * TOL and w["grad_fv"] < w["fp32_upstream_grad_fv"], w
 
 
+def test_wave_pairs_sharing_two_blocks_in_a_launch_with_its_own_list_kernel():
+    """20 images of 256^2 (5120 tiles of a mesh with five faces per tile): lists from the list kernel,
+    and a forward whose waves work in pairs that share the hits of two 8x8 blocks.  (Launches of
+    1536 to 4096 tiles take the same forward behind the fused setup + list kernel: the cases of
+    test_small_silhouette_launches_with_setup_and_lists_in_one_kernel.)"""
+    verts, faces = load_mesh(3)
+    B = 20
+    fv = camera_space_faces(verts, faces, B, seed=15)
+    sampled_compare("tiled_pairs_two_blocks_b20_256", fv, None, 256, False, "none", 256, check_images=(0, 11, 19),
+                    sigma=1e-4)
+
+
 def test_tiled_forward_on_a_raster_that_is_not_a_power_of_two():
     """Per-tile lists with partial tiles at the border and pixel centres that fp32 cannot hold
     exactly (S = 200: 13 x 13 tiles, the last 8 pixels wide); 16 images."""

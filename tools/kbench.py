@@ -62,10 +62,16 @@ CONFIGS = {
     "s320_rgb": (32, 320, False, 3, 1e-5, "surface", 6),
     "c2b2": (2, 256, False, 3, 1e-4, "none", 1),
     "c2b4": (4, 256, False, 3, 1e-4, "none", 1),
+    "c2b5": (5, 256, False, 3, 1e-4, "none", 1),
+    "c2b6": (6, 256, False, 3, 1e-4, "none", 1),
     "c2b12": (12, 256, False, 3, 1e-4, "none", 1),
     "c2b16": (16, 256, False, 3, 1e-4, "none", 1),
     "c2b20": (20, 256, False, 3, 1e-4, "none", 1),
+    "c2b24": (24, 256, False, 3, 1e-4, "none", 1),
+    "c2b28": (28, 256, False, 3, 1e-4, "none", 1),
     "c2b32": (32, 256, False, 3, 1e-4, "none", 1),
+    "hd_mask_b4": (4, 256, True, 4, 1e-5, "none", 1),
+    "hd_mask_b6": (6, 256, True, 4, 1e-5, "none", 1),
     "c2b512": (512, 256, False, 3, 1e-4, "none", 1),
     # per-GPU shares of a global batch of 512 at the HD mesh (5120 faces) and of the part-map renders
     "hd_rgb_b256": (256, 256, True, 4, 1e-5, "surface", 6),
