@@ -82,8 +82,8 @@ constexpr int kTile = 16;         // tile side in raster pixels
 #ifndef SV3D_TILED_TWO_BLOCKS_MIN_TILES
 #define SV3D_TILED_TWO_BLOCKS_MIN_TILES 12288   // two blocks per wave from this many tiles per launch
 #endif
-#ifndef SV3D_TILED_HALVES_TWO_BLOCKS_MIN_TILES
-#define SV3D_TILED_HALVES_TWO_BLOCKS_MIN_TILES 1536 // two waves per block: from this many tiles on they share two blocks
+#ifndef SV3D_TILED_SHARED_MIN_TILES
+#define SV3D_TILED_SHARED_MIN_TILES 1536            // ... from this many tiles on: the tile's four waves share all its hits
 #endif
 #ifndef SV3D_TILED_FUSED_MAX_TILES
 #define SV3D_TILED_FUSED_MAX_TILES 4096             // at most this many tiles: setup and lists in one launch
@@ -1446,12 +1446,9 @@ __device__ inline void make_tile_record(const float4 e0, const float4 e1, const 
 // tile-relative records in LDS (one thread per face: ids, then the faces' records -- two trips to
 // memory -- and one barrier), and every wave tests the list against its 8x8 blocks lane-parallel
 // and walks its hits.
-// HALVES = 2 (small launches, bound by their longest waves): two waves per block -- or, with NB = 2,
-// per pair of blocks -- which take the hits in turn and multiply their products together through
-// LDS.  With NB = 1 that is eight waves per tile: 2048 tiles are then two rounds of what the chip
-// holds at once, and the four SIMDs' visits keep the CU's LDS as busy as themselves; with NB = 2,
-// four waves per tile, everything up to 2048 tiles is resident at once and a record is read once
-// for two blocks (measured: better from 1536 tiles on, -5..11 %; worse at 1024 and 1280).
+// HALVES = 2 (NB = 1 only; the smallest launches, bound by their longest waves): eight waves, two per
+// block, which take the block's hits in turn and multiply their products together through LDS.
+// (From 1536 tiles on such launches take raster_forward_tiled_shared_kernel instead.)
 // NB = 1: four waves, one block each.  NB = 2 (the largest launches): two waves, rows 0-7 and 8-15,
 // each wave's lanes holding one pixel of the left and one of the right block; a visit's record is
 // then read from LDS once for both blocks.  The four broadcast ds_read_b128 of a visit take 16
@@ -1482,6 +1479,7 @@ __global__ __launch_bounds__(kThreads / NB * HALVES) void raster_forward_tiled_k
     const int *__restrict__ tcount, const unsigned short *__restrict__ tlist, const float4 *__restrict__ srec,
     const uint2 *__restrict__ pbox, int num_faces, float *__restrict__ rgba, float *__restrict__ saved, DevParams P)
 {
+    static_assert(HALVES == 1 || NB == 1, "two waves per block: one block per wave");
     __shared__ float4 s_trec[kTileCap * kTRecPad4];
     __shared__ float s_half[HALVES == 2 ? kThreads : 1];
     const int tiles_x = (P.S + kTile - 1) / kTile;
@@ -1551,13 +1549,11 @@ __global__ __launch_bounds__(kThreads / NB * HALVES) void raster_forward_tiled_k
                     }
                 }
                 unsigned long long mask0 = __ballot(hit0);
-                unsigned long long mask1 = __ballot(hit1);
-                if (HALVES == 2) {              // the hits (of either block) alternate between the two waves
-                    const unsigned long long any = mask0 | mask1;
-                    const bool mine = (hit0 || hit1) && (((hits_seen + __popcll(any & lane_lt)) & 1) == part);
-                    hits_seen += __popcll(any);
-                    mask0 = __ballot(mine && hit0);
-                    mask1 = __ballot(mine && hit1);
+                const unsigned long long mask1 = __ballot(hit1);
+                if (HALVES == 2) {              // the block's hits alternate between its two waves
+                    const bool mine = hit0 && (((hits_seen + __popcll(mask0 & lane_lt)) & 1) == part);
+                    hits_seen += __popcll(mask0);
+                    mask0 = __ballot(mine);
                 }
                 unsigned long long mask = mask0 | mask1;
                 while (mask) {
@@ -1605,14 +1601,10 @@ __global__ __launch_bounds__(kThreads / NB * HALVES) void raster_forward_tiled_k
         }
         SV3D_STAMP(3);
         if (HALVES == 2) {                      // n_list is uniform over the workgroup: every wave is here
-            if (part == 1) {
-                s_half[wave * 64 + lane] = A0;
-                if (NB == 2) s_half[(2 + wave) * 64 + lane] = A1;
-            }
+            if (part == 1) s_half[wave * 64 + lane] = A0;
             __syncthreads();
             if (part == 1) return;
             A0 *= s_half[wave * 64 + lane];
-            if (NB == 2) A1 *= s_half[(2 + wave) * 64 + lane];
         }
     } else if (HALVES == 2 && part == 1) {
         return;
@@ -1646,6 +1638,165 @@ __global__ __launch_bounds__(kThreads / NB * HALVES) void raster_forward_tiled_k
             alpha_b[ob] = alpha;
             if (!only_alpha) { rgba_b[ob] = P.bg0; rgba_b[ob + plane] = P.bg1; rgba_b[ob + 2 * plane] = P.bg2; }
         }
+    }
+    SV3D_STAMP(4);
+}
+
+// Small launches, bound by their longest waves: the tile's four waves take its hits IN TURN, each
+// hit for all of the tile's four 8x8 blocks that it touches (a lane holds one pixel of every block).
+// A wave's work is then a quarter of the tile's whatever the hits' spread over the blocks, a record
+// is read from LDS once per hit, and four waves per tile keep launches of up to 2048 tiles
+// resident at once (the eight waves of HALVES = 2 above are two rounds of what the chip holds from
+// 1024 tiles on, and their visits keep the CU's LDS as busy as its four SIMDs).  The waves' partial
+// products meet in LDS, and wave w finishes block w.  Measured against the eight-wave form: forward
+// -8 % at 8 images of 256^2, -13 % at 12; +5..16 % at 4 and 5 images (1024 and 1280 tiles: kept there).
+__global__ __launch_bounds__(kThreads) void raster_forward_tiled_shared_kernel(
+    const int *__restrict__ tcount, const unsigned short *__restrict__ tlist, const float4 *__restrict__ srec,
+    const uint2 *__restrict__ pbox, int num_faces, float *__restrict__ rgba, float *__restrict__ saved, DevParams P)
+{
+    __shared__ float4 s_trec[kTileCap * kTRecPad4];
+    __shared__ float s_part[4][4][64];          // [wave][block][lane]
+    const int tiles_x = (P.S + kTile - 1) / kTile;
+    const int b = blockIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int tile_x, tile_y;
+    tile_position(blockIdx.y, blockIdx.z, tiles_x, SV3D_SPIRAL, tile_x, tile_y);
+    const size_t tile = ((size_t)b * tiles_x + tile_y) * tiles_x + tile_x;
+    SV3D_STAMP(0);
+    const int my_id = (int)threadIdx.x < kTileCap ? (int)tlist[tile * kTileCap + threadIdx.x] : 0;
+    const int n_list = tcount[tile];
+#ifdef SV3D_TRACE
+    if (threadIdx.x == 0 && SV3D_WG_ID < 4096) {
+        g_phase[SV3D_WG_ID * 8 + 1] = __builtin_amdgcn_s_memrealtime() + (unsigned long long)(my_id < 0 ? 1 : 0);
+        g_phase[SV3D_WG_ID * 8 + 7] = (unsigned long long)n_list;
+    }
+#endif
+    const int S = P.S, F = num_faces;
+    const int tile_c0 = tile_x * kTile, tile_r0 = tile_y * kTile;
+    const int quad = lane >> 2, sub = lane & 3;
+    // lane -> pixel (lc, lr) of block 0; block k (0 .. 3) lies 8 (k & 1) columns and 8 (k >> 1) rows further
+    const int lc = (quad & 3) * 2 + (sub & 1), lr = (quad >> 2) * 2 + (sub >> 1);
+    float Afin = 1.f;                           // the product of this wave's block (block `wave`)
+    if (n_list > 0) {                                                   // uniform over the workgroup
+        float A[4] = {1.f, 1.f, 1.f, 1.f};      // products of this wave's visits' denominators, per block
+        const float ox[2] = {(float)(2 * lc - (kTile - 1)) * P.inv_S, (float)(2 * lc + 1) * P.inv_S};
+        const float oy[2] = {-(float)(2 * lr - (kTile - 1)) * P.inv_S, -(float)(2 * lr + 1) * P.inv_S};
+        const float bc = 8.f * P.inv_S, bh = 7.f * P.inv_S;             // block centres (-+bc, +-bc), half extent
+        const float cx_num = (float)(2 * tile_c0 + kTile - S), cy_num = (float)(S - kTile - 2 * tile_r0);
+        const unsigned long long lane_lt = (1ull << lane) - 1ull;
+        int hits_seen = 0;                                              // hits of the tile so far (wave-uniform)
+
+        auto process_window = [&](int nw, bool last) {
+            __syncthreads();
+            SV3D_STAMP(2);
+            for (int j0 = 0; j0 < nw; j0 += 64) {
+                const int j = j0 + lane;
+                bool h0 = false, h1 = false, h2 = false, h3 = false;
+                if (j < nw) {
+                    const float4 *r = &s_trec[j * kTRecPad4];
+                    const float4 r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3];
+                    const unsigned bits = __float_as_uint(r3.w);
+                    const int fc0 = bits & 15, fc1 = (bits >> 4) & 15, fr0 = (bits >> 8) & 15, fr1 = (bits >> 12) & 15;
+                    const bool face = bits < kNoFace;
+                    // the largest h over a block, per edge (see raster_forward_tiled_kernel): at the
+                    // tile's centre, then moved to the upper / lower and left / right block centres
+                    const float e0 = (fabsf(r0.x) + fabsf(r0.y)) * bh + r1.x;
+                    const float e1 = (fabsf(r1.y) + fabsf(r1.z)) * bh + r2.y;
+                    const float e2 = (fabsf(r2.z) + fabsf(r2.w)) * bh + r3.z;
+                    const float u0 = fmaf(r0.x, bc, e0), u1 = fmaf(r1.y, bc, e1), u2 = fmaf(r2.z, bc, e2);       // upper
+                    const float d0 = fmaf(-r0.x, bc, e0), d1 = fmaf(-r1.y, bc, e1), d2 = fmaf(-r2.z, bc, e2);    // lower
+                    const float ul = fminf(fmaf(r0.y, bc, u0), fminf(fmaf(r1.z, bc, u1), fmaf(r2.w, bc, u2)));
+                    const float ur = fminf(fmaf(-r0.y, bc, u0), fminf(fmaf(-r1.z, bc, u1), fmaf(-r2.w, bc, u2)));
+                    const float dl = fminf(fmaf(r0.y, bc, d0), fminf(fmaf(r1.z, bc, d1), fmaf(r2.w, bc, d2)));
+                    const float dr = fminf(fmaf(-r0.y, bc, d0), fminf(fmaf(-r1.z, bc, d1), fmaf(-r2.w, bc, d2)));
+                    const bool up = face && fr0 <= 7, down = face && fr1 >= 8, left = fc0 <= 7, right = fc1 >= 8;
+                    h0 = up && left && ul >= -P.visit_r;
+                    h1 = up && right && ur >= -P.visit_r;
+                    h2 = down && left && dl >= -P.visit_r;
+                    h3 = down && right && dr >= -P.visit_r;
+                }
+                const bool any = h0 || h1 || h2 || h3;
+                const unsigned long long m_any = __ballot(any);
+                const bool mine = any && (((hits_seen + __popcll(m_any & lane_lt)) & 3) == wave);
+                hits_seen += __popcll(m_any);
+                const unsigned long long m0 = __ballot(mine && h0), m1 = __ballot(mine && h1),
+                                         m2 = __ballot(mine && h2), m3 = __ballot(mine && h3);
+                unsigned long long mask = m0 | m1 | m2 | m3;
+                while (mask) {
+                    const int bit = __builtin_ctzll(mask);
+                    mask &= mask - 1;
+                    const float4 *r = &s_trec[(j0 + bit) * kTRecPad4];
+                    const float4 r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3];
+                    if ((m0 >> bit) & 1ull) A[0] *= tile_visit(r0, r1, r2, r3, ox[0], oy[0]);
+                    if ((m1 >> bit) & 1ull) A[1] *= tile_visit(r0, r1, r2, r3, ox[1], oy[0]);
+                    if ((m2 >> bit) & 1ull) A[2] *= tile_visit(r0, r1, r2, r3, ox[0], oy[1]);
+                    if ((m3 >> bit) & 1ull) A[3] *= tile_visit(r0, r1, r2, r3, ox[1], oy[1]);
+                }
+            }
+            if (!last) __syncthreads();
+        };
+
+        if (n_list <= kTileCap) {
+            if ((int)threadIdx.x < n_list) {    // one thread per face of the list builds its record in LDS
+                const float4 *q = reinterpret_cast<const float4 *>(
+                    reinterpret_cast<const char *>(srec + (size_t)b * F * 3) + __umul24((unsigned)my_id, 48u));
+                make_tile_record(q[0], q[1], q[2], (pbox + (size_t)b * F)[my_id], tile_c0, tile_r0, cx_num, cy_num, (float)S, P.inv_S,
+                                 &s_trec[threadIdx.x * kTRecPad4]);
+            }
+            process_window(n_list, true);
+        } else {
+            // more faces than a list holds: all of the image's faces, a window of slots at a time
+            const int tc1 = tile_c0 + kTile - 1, tr1 = tile_r0 + kTile - 1;
+            for (int f0 = 0; f0 < F; f0 += kTileCap) {                  // uniform over the workgroup
+                const int nw = min(kTileCap, F - f0);
+                if ((int)threadIdx.x < nw) {
+                    const size_t f = (size_t)b * F + f0 + threadIdx.x;
+                    const uint2 box = pbox[f];
+                    int a0, a1, b0, b1;
+                    unpack_box(box, a0, a1, b0, b1);
+                    float4 *o = &s_trec[threadIdx.x * kTRecPad4];
+                    if (!(a1 < tile_c0 || a0 > tc1 || b1 < tile_r0 || b0 > tr1)) {
+                        const float4 *q = srec + f * 3;
+                        make_tile_record(q[0], q[1], q[2], box, tile_c0, tile_r0, cx_num, cy_num, (float)S, P.inv_S, o);
+                    } else {
+                        o[3].w = __uint_as_float(kNoFace);
+                    }
+                }
+                process_window(nw, f0 + kTileCap >= F);
+            }
+        }
+        SV3D_STAMP(3);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) s_part[wave][k][lane] = A[k];
+        __syncthreads();
+        Afin = (s_part[0][wave][lane] * s_part[1][wave][lane]) * (s_part[2][wave][lane] * s_part[3][wave][lane]);
+    }
+    const bool only_alpha = P.alpha_only;
+    const int planes = only_alpha ? 1 : 4;
+    float *saved_b = saved + (size_t)b * S * S;
+    const int H = __builtin_amdgcn_readfirstlane(P.aa == 2 ? S >> 1 : S);
+    const unsigned plane = (unsigned)H * (unsigned)H;
+    float *rgba_b = rgba + (size_t)b * planes * plane;
+    float *alpha_b = rgba_b + (size_t)(planes - 1) * plane;
+    const float A = fminf(rcp(Afin), 1.f);
+    const float alpha = 1.f - A;
+    const int c = tile_c0 + lc + 8 * (wave & 1), row = tile_r0 + lr + 8 * (wave >> 1);
+    const bool inimg = c < S && row < S;
+    if (inimg) saved_b[__umul24((unsigned)row, (unsigned)S) + (unsigned)c] = A;
+    if (P.aa == 2) {
+        const unsigned ob = __umul24((unsigned)(row >> 1), (unsigned)H) + (unsigned)(c >> 1);
+        float v = inimg ? alpha : 0.f;
+        v += __shfl_xor(v, 1);
+        v += __shfl_xor(v, 2);
+        if (sub == 0 && inimg) {
+            alpha_b[ob] = 0.25f * v;
+            if (!only_alpha) { rgba_b[ob] = P.bg0; rgba_b[ob + plane] = P.bg1; rgba_b[ob + 2 * plane] = P.bg2; }
+        }
+    } else if (inimg) {
+        const unsigned ob = __umul24((unsigned)row, (unsigned)S) + (unsigned)c;
+        alpha_b[ob] = alpha;
+        if (!only_alpha) { rgba_b[ob] = P.bg0; rgba_b[ob + plane] = P.bg1; rgba_b[ob + 2 * plane] = P.bg2; }
     }
     SV3D_STAMP(4);
 }
@@ -2545,8 +2696,8 @@ int raster_forward_impl(const sv3d_raster_params *p, const float *face_vertices,
             if (ntiles >= SV3D_TILED_TWO_BLOCKS_MIN_TILES)
                 hipLaunchKernelGGL((raster_forward_tiled_kernel<2, 1>), tgrid, dim3(kThreads / 2), 0, s, tcount, tlist,
                                    srec, pbox, d.F, rgba_out, saved, d);
-            else if (tiled_halves(d) && ntiles >= SV3D_TILED_HALVES_TWO_BLOCKS_MIN_TILES)
-                hipLaunchKernelGGL((raster_forward_tiled_kernel<2, 2>), tgrid, dim3(kThreads), 0, s, tcount, tlist,
+            else if (tiled_halves(d) && ntiles >= SV3D_TILED_SHARED_MIN_TILES)
+                hipLaunchKernelGGL(raster_forward_tiled_shared_kernel, tgrid, dim3(kThreads), 0, s, tcount, tlist,
                                    srec, pbox, d.F, rgba_out, saved, d);
             else if (tiled_halves(d))
                 hipLaunchKernelGGL((raster_forward_tiled_kernel<1, 2>), tgrid, dim3(kThreads * 2), 0, s, tcount, tlist,

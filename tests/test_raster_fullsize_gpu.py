@@ -270,15 +270,19 @@ def test_tiled_forward_with_faces_many_tiles_long(B):
     assert w["img"] < 0.3 * TOL and w["grad_fv"] < w["fp32_upstream_grad_fv"], w
 
 
-def test_wave_pairs_sharing_two_blocks_in_a_launch_with_its_own_list_kernel():
+def test_four_waves_sharing_a_tiles_hits_in_a_launch_with_its_own_list_kernel():
     """20 images of 256^2 (5120 tiles of a mesh with five faces per tile): lists from the list kernel,
-    and a forward whose waves work in pairs that share the hits of two 8x8 blocks.  (Launches of
-    1536 to 4096 tiles take the same forward behind the fused setup + list kernel: the cases of
-    test_small_silhouette_launches_with_setup_and_lists_in_one_kernel.)"""
+    and the forward whose four waves take a tile's hits in turn, each for all four 8x8 blocks
+    (raster_forward_tiled_shared_kernel).  Launches of 1536 to 4096 tiles take the same forward behind
+    the fused setup + list kernel: the 8- and 12-image cases of
+    test_small_silhouette_launches_with_setup_and_lists_in_one_kernel; with lists that overflow,
+    test_tiled_forward_with_more_faces_in_a_tile_than_a_list_holds[2]; anti-aliased,
+    test_hd_mesh_at_the_reference_raster[none]; partial tiles,
+    test_tiled_forward_on_a_raster_that_is_not_a_power_of_two."""
     verts, faces = load_mesh(3)
     B = 20
     fv = camera_space_faces(verts, faces, B, seed=15)
-    sampled_compare("tiled_pairs_two_blocks_b20_256", fv, None, 256, False, "none", 256, check_images=(0, 11, 19),
+    sampled_compare("tiled_shared_hits_b20_256", fv, None, 256, False, "none", 256, check_images=(0, 11, 19),
                     sigma=1e-4)
 
 
