@@ -83,16 +83,13 @@ constexpr int kTile = 16;         // tile side in raster pixels
 #define SV3D_TILED_TWO_BLOCKS_MIN_TILES 12288   // two blocks per wave from this many tiles per launch
 #endif
 #ifndef SV3D_TILED_SHARED_MIN_TILES
-#define SV3D_TILED_SHARED_MIN_TILES 1536            // ... from this many tiles on: the tile's four waves share all its hits
+#define SV3D_TILED_SHARED_MIN_TILES 1536            // from this many tiles on a tile's four waves share all its hits
+#endif
+#ifndef SV3D_TILED_SHARED_MAX_TILES
+#define SV3D_TILED_SHARED_MAX_TILES 12287           // ... up to this many, for meshes of four faces per tile or more
 #endif
 #ifndef SV3D_TILED_FUSED_MAX_TILES
 #define SV3D_TILED_FUSED_MAX_TILES 4096             // at most this many tiles: setup and lists in one launch
-#endif
-#ifndef SV3D_TILED_HALVES_MAX_TILES
-#define SV3D_TILED_HALVES_MAX_TILES 2048            // ... and two waves per block in the forward
-#endif
-#ifndef SV3D_TILED_HALVES_MAX_TILES_DENSE
-#define SV3D_TILED_HALVES_MAX_TILES_DENSE 7168      // the same for meshes of at least four faces per tile
 #endif
 #ifndef SV3D_TILED_MAX_FACES_PER_TILE
 #define SV3D_TILED_MAX_FACES_PER_TILE 8             // faces of the mesh per tile of an image, at most
@@ -2541,13 +2538,24 @@ inline bool binning_lists_enabled(const DevParams &d)
 {
     return lists_fit(d) && !tiled_enabled(d) && launch_tiles(d) > SV3D_BINNING_LISTS_MIN_TILES;
 }
-inline bool tiled_halves(const DevParams &d)
+// Which form of the tiled forward a launch takes (all measured, tools/kbench.py):
+//   two_blocks: the largest launches; two waves per tile, each two 8x8 blocks.
+//   shared:     the tile's four waves share all its hits (raster_forward_tiled_shared_kernel): from 1536
+//               tiles up to 12287 for meshes of four faces per tile or more (8 .. 40 images of 1280
+//               faces at 256^2: -6 .. -13 % against the next two forms), 6144 for two, 3072 for one
+//               (2 / 3 images of 1280 faces at 512^2: -8 / -4 %; 6: none; 8: +3 %).
+//   pairs:      below 1536 tiles, meshes of two faces per tile or more: two waves per block taking its
+//               hits in turn (a mesh of fewer leaves a block's second wave next to nothing to share).
+//   blocks:     everything else: four waves per tile, one block each.
+enum class TiledForm { two_blocks, shared, pairs, blocks };
+inline TiledForm tiled_form(const DevParams &d)
 {
-    const long tiles = (d.S + kTile - 1) / kTile, n = launch_tiles(d);
-    // (a mesh of fewer than two faces per tile leaves a block's second wave next to nothing to share:
-    // 2 images at 512^2, 1.25 faces per tile, are 5 % faster with one wave per block)
-    return (n <= SV3D_TILED_HALVES_MAX_TILES && d.F >= 2 * tiles * tiles) ||
-           (n <= SV3D_TILED_HALVES_MAX_TILES_DENSE && d.F >= 4 * tiles * tiles);
+    const long tiles = (d.S + kTile - 1) / kTile, t2 = tiles * tiles, n = launch_tiles(d);
+    if (n >= SV3D_TILED_TWO_BLOCKS_MIN_TILES) return TiledForm::two_blocks;
+    const long shared_max = d.F >= 4 * t2 ? SV3D_TILED_SHARED_MAX_TILES : d.F >= 2 * t2 ? 6144 : d.F >= t2 ? 3072 : 0;
+    if (n >= SV3D_TILED_SHARED_MIN_TILES && n <= shared_max) return TiledForm::shared;
+    if (n < SV3D_TILED_SHARED_MIN_TILES && d.F >= 2 * t2) return TiledForm::pairs;
+    return TiledForm::blocks;
 }
 inline size_t tiled_bytes(const DevParams &d)
 {
@@ -2691,15 +2699,15 @@ int raster_forward_impl(const sv3d_raster_params *p, const float *face_vertices,
                                lists_lds_bytes(d.F), s, d, pbox, tcount, tlist, bx, tiles);
         if (ev_start) (void)hipEventRecord(ev_start, s);
         const dim3 tgrid((unsigned)d.B, (unsigned)tiles, (unsigned)tiles);
-        const long ntiles = (long)tiles * tiles * d.B;
         for (int rep = 0; rep < repeats; ++rep) {
-            if (ntiles >= SV3D_TILED_TWO_BLOCKS_MIN_TILES)
+            const TiledForm form = tiled_form(d);
+            if (form == TiledForm::two_blocks)
                 hipLaunchKernelGGL((raster_forward_tiled_kernel<2, 1>), tgrid, dim3(kThreads / 2), 0, s, tcount, tlist,
                                    srec, pbox, d.F, rgba_out, saved, d);
-            else if (tiled_halves(d) && ntiles >= SV3D_TILED_SHARED_MIN_TILES)
+            else if (form == TiledForm::shared)
                 hipLaunchKernelGGL(raster_forward_tiled_shared_kernel, tgrid, dim3(kThreads), 0, s, tcount, tlist,
                                    srec, pbox, d.F, rgba_out, saved, d);
-            else if (tiled_halves(d))
+            else if (form == TiledForm::pairs)
                 hipLaunchKernelGGL((raster_forward_tiled_kernel<1, 2>), tgrid, dim3(kThreads * 2), 0, s, tcount, tlist,
                                    srec, pbox, d.F, rgba_out, saved, d);
             else

@@ -33,6 +33,10 @@ CONFIGS = {
     "ref_vert8": (64, 256, True, 3, 1e-5, "vertex8", 1),    # eight part maps in one pass
     "ref_mask_b8": (8, 256, True, 3, 1e-5, "none", 1),
     "ref_mask_b3": (3, 256, True, 3, 1e-5, "none", 1),
+    "ref_mask_b4": (4, 256, True, 3, 1e-5, "none", 1),
+    "ref_mask_b6": (6, 256, True, 3, 1e-5, "none", 1),
+    "hd_mask_b8": (8, 256, True, 4, 1e-5, "none", 1),
+    "c2b40": (40, 256, False, 3, 1e-4, "none", 1),
     "ref_mask_b2": (2, 256, True, 3, 1e-5, "none", 1),
     "hd_mask_b2": (2, 256, True, 4, 1e-5, "none", 1),         # 5120 faces in a small launch
     # colour modes at 51 and 26 raster pixels per face: where the backward's row intervals start to pay
