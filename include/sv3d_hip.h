@@ -158,7 +158,8 @@ int sv3d_raster_backward_timed_n(const sv3d_raster_params *p, const float *textu
                                  void *stream, void *ev_start, void *ev_stop, int32_t repeats);
 
 /* Name of the kernel the events of sv3d_raster_forward_timed(_n) bracket for this configuration
- * ("raster_forward_kernel" or "raster_forward_tiled_kernel"; from_mesh != 0: as called through
+ * ("raster_forward_kernel", "raster_forward_tiled_kernel" or "raster_forward_tiled_shared_kernel";
+ * from_mesh != 0: as called through
  * sv3d_render_forward), so that a benchmark can match its timings with a profiler's rows.  ""
  * for parameters the other entry points refuse.  No counterpart in the reference. */
 const char *sv3d_raster_forward_kernel_name(const sv3d_raster_params *p, int32_t from_mesh);

@@ -2859,7 +2859,8 @@ extern "C" const char *sv3d_raster_forward_kernel_name(const sv3d_raster_params 
 {
     DevParams d;
     if (make_dev_params(p, d) != SV3D_OK) return "";
-    return forward_route(d, from_mesh != 0).tiled ? "raster_forward_tiled_kernel" : "raster_forward_kernel";
+    if (!forward_route(d, from_mesh != 0).tiled) return "raster_forward_kernel";
+    return tiled_form(d) == TiledForm::shared ? "raster_forward_tiled_shared_kernel" : "raster_forward_tiled_kernel";
 }
 
 extern "C" int sv3d_raster_forward_timed_n(const sv3d_raster_params *p, const float *face_vertices,

@@ -214,8 +214,11 @@ def test_c_abi_argument_validation_without_gpu():
     plain = 8 * 1280 * (32 * 4 + 8) + 8 * 20 * 8
     assert rec == plain + 8 * 256 * 4 + 16 + 8 * 1280 * 48 + 8 * 256 * 128 * 2
     assert saved == 8 * 256 * 256 * 4 and ws == 0
-    assert _lib.lib().sv3d_raster_forward_kernel_name(ctypes.byref(p), 0) == b"raster_forward_tiled_kernel"
+    # 2048 tiles of a mesh with five faces per tile: the form whose four waves share a tile's hits
+    assert _lib.lib().sv3d_raster_forward_kernel_name(ctypes.byref(p), 0) == b"raster_forward_tiled_shared_kernel"
     assert _lib.lib().sv3d_raster_forward_kernel_name(ctypes.byref(p), 1) == b"raster_forward_kernel"
+    p64 = _lib.make_params(64, 1280, 256, 1, 0, 1, True, (0, 0, 0), 1, 100, 1e-3, 1e-4, 1e-10, 1e-4)
+    assert _lib.lib().sv3d_raster_forward_kernel_name(ctypes.byref(p64), 0) == b"raster_forward_tiled_kernel"
     p.texture_mode = 1
     p.texture_res = 6
     # a colour launch of this size keeps the plain layout (lists from 4096 tiles on)

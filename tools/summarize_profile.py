@@ -24,7 +24,7 @@ def load(sub):
 
 
 def short(name):
-    for k in ("raster_forward_tiled_kernel", "raster_tile_lists_kernel", "raster_setup_lists_kernel", "raster_forward_kernel", "raster_backward_kernel", "raster_setup_kernel", "raster_prep_kernel",
+    for k in ("raster_forward_tiled_shared_kernel", "raster_forward_tiled_kernel", "raster_tile_lists_kernel", "raster_setup_lists_kernel", "raster_forward_kernel", "raster_backward_kernel", "raster_setup_kernel", "raster_prep_kernel",
               "chamfer_nn_small_kernel", "chamfer_nn_kernel", "chamfer_grad_kernel", "face_gather_kernel",
               "face_scatter_kernel"):
         if k in name:
