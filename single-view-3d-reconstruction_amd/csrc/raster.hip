@@ -1667,6 +1667,10 @@ __global__ __launch_bounds__(kThreads) void raster_forward_tiled_shared_kernel(
     if (threadIdx.x == 0 && SV3D_WG_ID < 4096) {
         g_phase[SV3D_WG_ID * 8 + 1] = __builtin_amdgcn_s_memrealtime() + (unsigned long long)(my_id < 0 ? 1 : 0);
         g_phase[SV3D_WG_ID * 8 + 7] = (unsigned long long)n_list;
+        unsigned hwid, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        g_phase[SV3D_WG_ID * 8 + 5] = ((unsigned long long)xcc << 32) | hwid;
     }
 #endif
     const int S = P.S, F = num_faces;

@@ -63,3 +63,28 @@ for i in range(4):
     print("%-32s non-empty: mean %.2f p50 %.2f p90 %.2f max %.2f us" % (names[i], d.mean(), np.median(d), np.percentile(d, 90), d.max()))
 d = t[full, 4] - t[full, 0]
 print("lifetime non-empty: mean %.2f p90 %.2f max %.2f us; empty: mean %.2f us" % (d.mean(), np.percentile(d, 90), d.max(), (t[~full, 4] - t[~full, 0]).mean() if (~full).any() else 0))
+
+hw = pb[: n * 8].reshape(n, 8)[:, 5]
+if hw.any():
+    xcc = (hw >> np.uint64(32)).astype(np.int64) & 0xf
+    hwid = (hw & np.uint64(0xffffffff)).astype(np.int64)
+    cu = (hwid >> 8) & 0xf
+    sh = (hwid >> 12) & 0x1
+    se = (hwid >> 13) & 0x7
+    key = ((xcc * 8 + se) * 2 + sh) * 16 + cu
+    uk = np.unique(key)
+    load = np.array([nl[key == k].sum() for k in uk], dtype=np.float64)
+    cnt = np.array([(key == k).sum() for k in uk])
+    fin = np.array([t[key == k, 4].max() - base for k in uk])
+    print("CUs seen %d; workgroups per CU min %d mean %.1f max %d" % (len(uk), cnt.min(), cnt.mean(), cnt.max()))
+    print("listed faces per CU (sum over its tiles): min %.0f mean %.0f p90 %.0f max %.0f" % (load.min(), load.mean(), np.percentile(load, 90), load.max()))
+    print("CU finish time: min %.1f mean %.1f max %.1f us; correlation with its listed faces %.2f" % (fin.min(), fin.mean(), fin.max(), np.corrcoef(load, fin)[0, 1]))
+    order = np.argsort(t[:, 0])
+    first = order[:64]
+    print("first 64 workgroups started (wg id: cu key): " + " ".join("%d:%d" % (i, key[i]) for i in first[:32]))
+    if os.environ.get("SV3D_TRACE_PLACEMENT"):
+        for k in uk[:6]:
+            ids = np.nonzero(key == k)[0]
+            print("cu key %d (xcc %d): workgroups %s  lists %s  starts %s" % (k, xcc[ids[0]], ids.tolist(), nl[ids].tolist(),
+                  np.round(t[ids, 0] - base, 1).tolist()))
+        print("xcc of workgroup id mod 8:", [int(np.bincount(xcc[np.arange(n) % 8 == r], minlength=8).argmax()) for r in range(8)])
