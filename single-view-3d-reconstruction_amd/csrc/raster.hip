@@ -33,9 +33,9 @@
 #ifdef SV3D_TRACE
 // Diagnostic build only: per-workgroup start / end stamps and phase stamps of the forward kernel.
 __device__ unsigned long long g_trace[4 * 16384];
-__device__ unsigned long long g_phase[8 * 4096];
+__device__ unsigned long long g_phase[8 * 16384];
 #define SV3D_WG_ID ((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x)
-#define SV3D_STAMP(i) do { if (threadIdx.x == 0 && SV3D_WG_ID < 4096) g_phase[SV3D_WG_ID * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define SV3D_STAMP(i) do { if (threadIdx.x == 0 && SV3D_WG_ID < 16384) g_phase[SV3D_WG_ID * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 extern "C" int sv3d_debug_read_trace(void *host_out, size_t bytes)
 {
     return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_trace), bytes, 0, hipMemcpyDeviceToHost);
@@ -1174,7 +1174,7 @@ __attribute__((amdgpu_waves_per_eu(MODE == SV3D_TEX_VERTEX8 ? 7 : 8))) void rast
     }
     SV3D_STAMP(6);
 #ifdef SV3D_TRACE
-    if (lane == 0 && SV3D_WG_ID < 4096 && part == 0) {
+    if (lane == 0 && SV3D_WG_ID < 16384 && part == 0) {
         unsigned hwid;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
         unsigned xcc;
@@ -1493,9 +1493,13 @@ __global__ __launch_bounds__(kThreads / NB * HALVES) void raster_forward_tiled_k
     const int my_id = (int)threadIdx.x < kTileCap ? (int)tlist[tile * kTileCap + threadIdx.x] : 0;
     const int n_list = tcount[tile];
 #ifdef SV3D_TRACE
-    if (threadIdx.x == 0 && SV3D_WG_ID < 4096) {
+    if (threadIdx.x == 0 && SV3D_WG_ID < 16384) {
         g_phase[SV3D_WG_ID * 8 + 1] = __builtin_amdgcn_s_memrealtime() + (unsigned long long)(my_id < 0 ? 1 : 0);
         g_phase[SV3D_WG_ID * 8 + 7] = (unsigned long long)n_list;
+        unsigned hwid, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        g_phase[SV3D_WG_ID * 8 + 5] = ((unsigned long long)xcc << 32) | hwid;
     }
 #endif
     const int S = P.S, F = num_faces;
@@ -1664,7 +1668,7 @@ __global__ __launch_bounds__(kThreads) void raster_forward_tiled_shared_kernel(
     const int my_id = (int)threadIdx.x < kTileCap ? (int)tlist[tile * kTileCap + threadIdx.x] : 0;
     const int n_list = tcount[tile];
 #ifdef SV3D_TRACE
-    if (threadIdx.x == 0 && SV3D_WG_ID < 4096) {
+    if (threadIdx.x == 0 && SV3D_WG_ID < 16384) {
         g_phase[SV3D_WG_ID * 8 + 1] = __builtin_amdgcn_s_memrealtime() + (unsigned long long)(my_id < 0 ? 1 : 0);
         g_phase[SV3D_WG_ID * 8 + 7] = (unsigned long long)n_list;
         unsigned hwid, xcc;

@@ -42,8 +42,8 @@ stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
 for _ in range(20):
     assert lib.sv3d_raster_forward(ctypes.byref(p), vp(fv), None, vp(rgba), vp(rec), vp(saved), stream) == 0
 torch.cuda.synchronize()
-n = min(((S + 15) // 16) ** 2 * B, 4096)
-pb = np.zeros(8 * 4096, dtype=np.uint64)
+n = min(((S + 15) // 16) ** 2 * B, 16384)
+pb = np.zeros(8 * 16384, dtype=np.uint64)
 lib.sv3d_debug_read_phase.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
 assert lib.sv3d_debug_read_phase(pb.ctypes.data_as(ctypes.c_void_p), pb.nbytes) == 0
 ph = pb[: n * 8].reshape(n, 8).astype(np.int64)
@@ -57,6 +57,11 @@ st = np.sort(t[:, 0] - base)
 print("workgroups started by t us: " + "  ".join("%g:%d" % (x, int((st <= x).sum())) for x in (0.5, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 12)))
 en = np.sort(t[:, 4] - base)
 print("workgroups finished by t us: " + "  ".join("%g:%d" % (x, int((en <= x).sum())) for x in (1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 12, 14)))
+span = t[:, 4].max() - base
+if span > 16:
+    grid = np.linspace(0, span, 13)[1:]
+    print("started by:  " + "  ".join("%.0f:%d" % (x, int((st <= x).sum())) for x in grid))
+    print("finished by: " + "  ".join("%.0f:%d" % (x, int((en <= x).sum())) for x in grid))
 names = ["start -> list length here", "-> records built (barrier)", "-> first wave's visits done", "-> end"]
 for i in range(4):
     d = t[full, i + 1] - t[full, i]
