@@ -34,6 +34,9 @@ CONFIGS = {
     "ref_mask_b8": (8, 256, True, 3, 1e-5, "none", 1),
     "ref_mask_b3": (3, 256, True, 3, 1e-5, "none", 1),
     "ref_mask_b4": (4, 256, True, 3, 1e-5, "none", 1),
+    "ref_mask_b12": (12, 256, True, 3, 1e-5, "none", 1),
+    "ref_rgb_b12": (12, 256, True, 3, 1e-5, "surface", 6),
+    "hd_mask_b3": (3, 256, True, 4, 1e-5, "none", 1),
     "ref_mask_b6": (6, 256, True, 3, 1e-5, "none", 1),
     "hd_mask_b8": (8, 256, True, 4, 1e-5, "none", 1),
     "c2b40": (40, 256, False, 3, 1e-4, "none", 1),
